@@ -1,0 +1,112 @@
+/*
+ * kmer_oracle.h -- CPU restatement of the reference's k-mer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and there only as the checker / the timed CPU baseline.  The product
+ * (libdnagpu.so, libdna_glue.so) never links, loads or calls it.
+ *
+ * Parity pinning: the reference (a PostgreSQL extension, /root/reference/dna.c) cannot be
+ * built in this image (needs the PostgreSQL server headers + PGXS, neither present), and no
+ * stand-in headers are written for it.  This restatement is therefore pinned by
+ *   (1) the expected outputs the reference's own test script and README hold for this path
+ *       (test.sql:46-119, README.md:64-134) -- tests/golden/reference_vectors.json, and
+ *   (2) the packed-word / key / hash values recorded in SURVEY.md section 8(a), which the
+ *       survey captured from the reference's compiled code -- tests/golden/survey_vectors.json.
+ * kmer_hash values (PostgreSQL's hash_any) have no expectation in the reference's own tests:
+ * parity for that one function is "unpinned" beyond (2).
+ *
+ * Every function cites the reference lines it follows (file:line into /root/reference).
+ */
+#ifndef KMER_ORACLE_H
+#define KMER_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (mirror the ereport() sites of dna.c; message text via orc_strerror) */
+enum {
+    ORC_OK = 0,
+    ORC_ERR_INVALID_K = 1,           /* dna.c:772-773 */
+    ORC_ERR_QKMER_LEN_MISMATCH = 2,  /* dna.c:1106-1108 */
+    ORC_ERR_PREFIX_TOO_LONG = 3,     /* dna.c:854-856 */
+    ORC_ERR_DNA_EMPTY = 4,           /* dna.c:160-161 */
+    ORC_ERR_DNA_BAD_CHAR = 5,        /* dna.c:165-166, 124-125 */
+    ORC_ERR_KMER_EMPTY = 6,          /* dna.c:460-461 */
+    ORC_ERR_KMER_TOO_LONG = 7,       /* dna.c:466-467 */
+    ORC_ERR_KMER_BAD_CHAR = 8,       /* dna.c:472-473 */
+    ORC_ERR_QKMER_EMPTY = 9,         /* dna.c:877-878 */
+    ORC_ERR_QKMER_TOO_LONG = 10,     /* dna.c:883-884 */
+    ORC_ERR_QKMER_BAD_CHAR = 11,     /* dna.c:893-894 */
+    ORC_ERR_NOMEM = 12
+};
+const char *orc_strerror(int code);
+
+/* ---- dna type: text -> 2-bit packed words (dna.c:114-128, 159-171, 178-202) ---- */
+uint64_t orc_dna_num_words(uint64_t n_bases);
+int orc_dna_encode(const char *seq, uint64_t *words /* zeroed, orc_dna_num_words(strlen) */);
+void orc_dna_decode(const uint64_t *words, uint64_t n_bases, char *out /* n_bases+1 */);
+
+/* ---- kmer type (dna.c:397-420, 428-452, 457-479, 487-515) ---- */
+int orc_kmer_encode(const char *seq, int32_t *length, uint64_t *bits);
+void orc_kmer_decode(uint64_t bits, int k, char *out /* k+1 */);
+
+/* ---- generate_kmers (dna.c:743-837) ----
+ * Faithful form: per k-mer, loop A decodes 2-bit codes to characters (803-820), then kmer_make
+ * validates (457-479) and re-encodes (397-420).  64-bit positions; length < k yields 0 rows
+ * (documented divergence from the reference's unsigned underflow at dna.c:781). */
+int orc_generate_kmers_count(uint64_t n_bases, int k, uint64_t *n_kmers);
+int orc_generate_kmers(const uint64_t *words, uint64_t n_bases, int k,
+                       uint64_t first, uint64_t count, uint64_t *out_keys);
+/* Same result by word arithmetic (bits [2p, 2p+2k) of the stream); cross-checked against the
+ * faithful form in tests, used where the faithful form would take minutes. */
+int orc_generate_kmers_fast(const uint64_t *words, uint64_t n_bases, int k,
+                            uint64_t first, uint64_t count, uint64_t *out_keys);
+
+/* ---- operators ---- */
+int orc_kmer_eq(int32_t len1, uint64_t bits1, int32_t len2, uint64_t bits2);       /* dna.c:655-668 */
+uint32_t orc_kmer_hash(uint64_t bits);                                             /* dna.c:722-735 */
+uint32_t orc_pg_hash_uint32(uint32_t k); /* PostgreSQL hash_bytes_uint32: known-answer anchor */
+int orc_starts_with(int32_t klen, uint64_t kbits, int32_t plen, uint64_t pbits, int *result); /* dna.c:842-866 */
+int orc_qkmer_validate(const char *pattern);                                       /* dna.c:876-900 */
+int orc_contains(const char *pattern, int32_t klen, uint64_t kbits, int *result);  /* dna.c:1064-1135 */
+
+/* fused scans = generate_kmers + WHERE <operator>, rows in position order (test.sql:61-92) */
+int orc_generate_kmers_contains(const uint64_t *words, uint64_t n_bases, int k, const char *pattern,
+                                uint64_t *out_keys, uint64_t *out_pos, uint64_t cap, uint64_t *n_out);
+int orc_generate_kmers_starts_with(const uint64_t *words, uint64_t n_bases, int k,
+                                   int32_t plen, uint64_t pbits,
+                                   uint64_t *out_keys, uint64_t *out_pos, uint64_t cap, uint64_t *n_out);
+int orc_generate_kmers_equals(const uint64_t *words, uint64_t n_bases, int k,
+                              int32_t qlen, uint64_t qbits,
+                              uint64_t *out_keys, uint64_t *out_pos, uint64_t cap, uint64_t *n_out);
+
+/* ---- GROUP BY kmer, count(*) (test.sql:95-119): hash aggregate driven by kmer_hash +
+ * kmer_eq like PostgreSQL's HashAggregate; groups are returned sorted by key (canonical form;
+ * PostgreSQL's own group order is unspecified).  Caller frees with orc_free. */
+int orc_count_keys(const uint64_t *keys, uint64_t n, uint64_t **out_keys, uint64_t **out_counts,
+                   uint64_t *n_distinct);
+int orc_count_kmers(const uint64_t *words, uint64_t n_bases, int k, int faithful,
+                    uint64_t **out_keys, uint64_t **out_counts, uint64_t *n_distinct);
+void orc_free(void *p);
+
+/* total / distinct / unique summary (test.sql:107-119) and an order-independent checksum */
+void orc_hist_summary(const uint64_t *keys, const uint64_t *counts, uint64_t n_distinct,
+                      uint64_t *total, uint64_t *unique, uint64_t *checksum);
+uint64_t orc_pair_mix(uint64_t key, uint64_t count);
+
+/* ---- synthetic input: word w = splitmix64(seed + w), tail bits zeroed ---- */
+uint64_t orc_splitmix64(uint64_t x);
+void orc_synth_words(uint64_t seed, uint64_t n_bases, uint64_t *words);
+/* repeat-rich variant: a motif_len-base motif (taken from the synthetic stream itself) is tiled
+ * over the second half of the sequence */
+void orc_synth_words_repeat(uint64_t seed, uint64_t n_bases, uint64_t motif_len, uint64_t *words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
