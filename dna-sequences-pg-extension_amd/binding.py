@@ -1,0 +1,355 @@
+"""ctypes binding of include/dnagpu.h (libdnagpu.so).  One method per C entry point; numpy arrays
+in and out; errors raise DnaGpuError carrying the status code and the reference's message text."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK = 0
+ERR_INVALID_K = 1
+ERR_QKMER_LEN_MISMATCH = 2
+ERR_PREFIX_TOO_LONG = 3
+ERR_QKMER_INVALID = 4
+ERR_BAD_ARG = 5
+ERR_TOO_LARGE = 6
+ERR_NO_DEVICE = 7
+ERR_OOM = 8
+ERR_HIP = 9
+
+FILTER_EQUALS = 1
+FILTER_STARTS_WITH = 2
+FILTER_CONTAINS = 3
+
+MAX_PHASES = 16
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class _FilterC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("length", C.c_int32), ("bits", C.c_uint64),
+                ("pattern", C.c_char * 36), ("reserved", C.c_int32)]
+
+
+class _PhaseTimes(C.Structure):
+    _fields_ = [("n", C.c_int), ("names", C.c_char_p * MAX_PHASES), ("ms", C.c_float * MAX_PHASES)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdnagpu.so")
+
+
+def lib():
+    """Loads libdnagpu.so; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.dnagpu_strerror.restype = C.c_char_p
+    L.dnagpu_strerror.argtypes = [C.c_int]
+    L.dnagpu_last_error.restype = C.c_char_p
+    L.dnagpu_abi_version.restype = C.c_int
+    L.dnagpu_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.dnagpu_destroy.argtypes = [vp]
+    L.dnagpu_destroy.restype = None
+    L.dnagpu_synchronize.argtypes = [vp]
+    L.dnagpu_stream.argtypes = [vp]
+    L.dnagpu_stream.restype = vp
+    L.dnagpu_trim.argtypes = [vp]
+    L.dnagpu_device_bytes.argtypes = [vp]
+    L.dnagpu_device_bytes.restype = C.c_uint64
+    L.dnagpu_dna_upload.argtypes = [vp, u64p, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_dna_wrap.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_dna_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_dna_download.argtypes = [vp, vp, u64p]
+    L.dnagpu_dna_length.argtypes = [vp]
+    L.dnagpu_dna_length.restype = C.c_uint64
+    L.dnagpu_dna_device_words.argtypes = [vp]
+    L.dnagpu_dna_device_words.restype = vp
+    L.dnagpu_dna_free.argtypes = [vp, vp]
+    L.dnagpu_dna_free.restype = None
+    L.dnagpu_kmer_count.argtypes = [C.c_uint64, C.c_int, u64p]
+    L.dnagpu_generate_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, vp, C.c_int]
+    L.dnagpu_generate_kmers_filtered.argtypes = [vp, vp, C.c_int, C.POINTER(_FilterC), C.c_uint64,
+                                                 C.c_uint64, vp, vp, C.c_uint64, u64p, C.c_int]
+    L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_count_keys.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.dnagpu_hist_distinct.argtypes = [vp]
+    L.dnagpu_hist_distinct.restype = C.c_uint64
+    L.dnagpu_hist_total.argtypes = [vp]
+    L.dnagpu_hist_total.restype = C.c_uint64
+    L.dnagpu_hist_device_keys.argtypes = [vp]
+    L.dnagpu_hist_device_keys.restype = vp
+    L.dnagpu_hist_device_counts.argtypes = [vp]
+    L.dnagpu_hist_device_counts.restype = vp
+    L.dnagpu_hist_download.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u64p, u64p]
+    L.dnagpu_hist_summary.argtypes = [vp, vp, u64p, u64p, u64p]
+    L.dnagpu_hist_free.argtypes = [vp, vp]
+    L.dnagpu_hist_free.restype = None
+    L.dnagpu_partition_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp), u64p]
+    L.dnagpu_buffer_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_buffer_free.argtypes = [vp, vp]
+    L.dnagpu_buffer_free.restype = None
+    L.dnagpu_kmer_hash.argtypes = [vp, vp, C.c_uint64, vp, C.c_int]
+    L.dnagpu_kmer_match.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(_FilterC), vp, C.c_int]
+    L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
+    L.dnagpu_set_profiling.argtypes = [vp, C.c_int]
+    _LIB = L
+    return L
+
+
+class DnaGpuError(Exception):
+    def __init__(self, code):
+        self.code = code
+        self.message = lib().dnagpu_strerror(code).decode()
+        detail = lib().dnagpu_last_error().decode()
+        super().__init__(self.message + (f" [{detail}]" if detail and code >= ERR_BAD_ARG else ""))
+
+
+def _chk(rc):
+    if rc != OK:
+        raise DnaGpuError(rc)
+
+
+def strerror(code):
+    return lib().dnagpu_strerror(code).decode()
+
+
+def abi_version():
+    return lib().dnagpu_abi_version()
+
+
+def kmer_count(n_bases, k):
+    out = C.c_uint64()
+    _chk(lib().dnagpu_kmer_count(n_bases, k, C.byref(out)))
+    return out.value
+
+
+class Filter:
+    """Right-hand side of a WHERE operator on generate_kmers rows."""
+
+    def __init__(self, kind, length=0, bits=0, pattern=""):
+        self.c = _FilterC()
+        self.c.kind = kind
+        self.c.length = length
+        self.c.bits = int(bits)
+        self.c.pattern = pattern.encode()[:35]
+
+    @staticmethod
+    def equals(length, bits):          # kmer = q
+        return Filter(FILTER_EQUALS, length, bits)
+
+    @staticmethod
+    def starts_with(length, bits):     # kmer ^@ prefix
+        return Filter(FILTER_STARTS_WITH, length, bits)
+
+    @staticmethod
+    def contains(pattern):             # qkmer @> kmer
+        return Filter(FILTER_CONTAINS, 0, 0, pattern)
+
+
+class Dna:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def n_bases(self):
+        return int(lib().dnagpu_dna_length(self.h))
+
+    @property
+    def device_words(self):
+        return lib().dnagpu_dna_device_words(self.h)
+
+    def download(self):
+        nw = (self.n_bases + 31) // 32
+        out = np.empty(max(nw, 1), dtype=np.uint64)
+        _chk(lib().dnagpu_dna_download(self.ctx.h, self.h, out.ctypes.data_as(u64p)))
+        return out[:nw]
+
+    def free(self):
+        if self.h:
+            lib().dnagpu_dna_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Hist:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def distinct(self):
+        return int(lib().dnagpu_hist_distinct(self.h))
+
+    @property
+    def total(self):
+        return int(lib().dnagpu_hist_total(self.h))
+
+    @property
+    def device_keys(self):
+        return lib().dnagpu_hist_device_keys(self.h)
+
+    @property
+    def device_counts(self):
+        return lib().dnagpu_hist_device_counts(self.h)
+
+    def download(self, first=0, count=None):
+        if count is None:
+            count = self.distinct - first
+        keys = np.empty(max(count, 1), dtype=np.uint64)
+        counts = np.empty(max(count, 1), dtype=np.uint64)
+        _chk(lib().dnagpu_hist_download(self.ctx.h, self.h, first, count, keys.ctypes.data_as(u64p),
+                                        counts.ctypes.data_as(u64p)))
+        return keys[:count], counts[:count]
+
+    def summary(self):
+        """(total, distinct, unique, checksum) -- same tuple as the oracle's hist_summary"""
+        t, u, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().dnagpu_hist_summary(self.ctx.h, self.h, C.byref(t), C.byref(u), C.byref(c)))
+        return t.value, self.distinct, u.value, c.value
+
+    def free(self):
+        if self.h:
+            lib().dnagpu_hist_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().dnagpu_init(device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dnagpu_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        _chk(lib().dnagpu_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().dnagpu_stream(self.h)
+
+    def trim(self):
+        _chk(lib().dnagpu_trim(self.h))
+
+    def device_bytes(self):
+        return int(lib().dnagpu_device_bytes(self.h))
+
+    def set_profiling(self, on):
+        _chk(lib().dnagpu_set_profiling(self.h, int(bool(on))))
+
+    def last_phase_times(self):
+        pt = _PhaseTimes()
+        _chk(lib().dnagpu_last_phase_times(self.h, C.byref(pt)))
+        return [(pt.names[i].decode(), float(pt.ms[i])) for i in range(pt.n)]
+
+    # ---- dna
+    def upload(self, words, n_bases):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        if w.size < (n_bases + 31) // 32:
+            raise ValueError("words shorter than n_bases")
+        h = C.c_void_p()
+        _chk(lib().dnagpu_dna_upload(self.h, w.ctypes.data_as(u64p), n_bases, C.byref(h)))
+        return Dna(self, h)
+
+    def wrap(self, dev_ptr, n_words, n_bases):
+        h = C.c_void_p()
+        _chk(lib().dnagpu_dna_wrap(self.h, dev_ptr, n_words, n_bases, C.byref(h)))
+        return Dna(self, h)
+
+    def synth(self, seed, n_bases, motif_len=0):
+        h = C.c_void_p()
+        _chk(lib().dnagpu_dna_synth(self.h, seed, n_bases, motif_len, C.byref(h)))
+        return Dna(self, h)
+
+    # ---- generate_kmers
+    def generate_kmers(self, dna, k, first=0, count=None):
+        total = kmer_count(dna.n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        out = np.empty(max(count, 1), dtype=np.uint64)
+        _chk(lib().dnagpu_generate_kmers(self.h, dna.h, k, first, count, out.ctypes.data, 0))
+        return out[:count]
+
+    def generate_kmers_device(self, dna, k, first, count, dev_out):
+        _chk(lib().dnagpu_generate_kmers(self.h, dna.h, k, first, count, dev_out, 1))
+
+    def generate_kmers_filtered(self, dna, k, flt, first=0, count=None, cap=None, want_keys=True,
+                                want_pos=True):
+        """-> (keys, positions, n_total_matches)"""
+        total = kmer_count(dna.n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        if cap is None:
+            cap = count
+        keys = np.empty(max(cap, 1), dtype=np.uint64) if want_keys else None
+        pos = np.empty(max(cap, 1), dtype=np.uint64) if want_pos else None
+        n = C.c_uint64()
+        _chk(lib().dnagpu_generate_kmers_filtered(
+            self.h, dna.h, k, C.byref(flt.c), first, count,
+            keys.ctypes.data if want_keys else None, pos.ctypes.data if want_pos else None,
+            cap, C.byref(n), 0))
+        m = min(n.value, cap)
+        return (keys[:m] if want_keys else None, pos[:m] if want_pos else None, n.value)
+
+    def count_matches_device(self, dna, k, flt, first, count, dev_keys=None, dev_pos=None, cap=0):
+        n = C.c_uint64()
+        _chk(lib().dnagpu_generate_kmers_filtered(self.h, dna.h, k, C.byref(flt.c), first, count,
+                                                  dev_keys, dev_pos, cap, C.byref(n), 1))
+        return n.value
+
+    # ---- GROUP BY
+    def count_kmers(self, dna, k, first=0, count=None):
+        total = kmer_count(dna.n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_kmers(self.h, dna.h, k, first, count, C.byref(h)))
+        return Hist(self, h)
+
+    def count_keys_device(self, dev_keys, n, k):
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_keys(self.h, dev_keys, n, k, C.byref(h)))
+        return Hist(self, h)
+
+    def partition_kmers(self, dna, k, first, count, n_owners):
+        """-> (device pointer to `count` keys grouped by owner, offsets[n_owners+1])"""
+        ptr = C.c_void_p()
+        offs = np.zeros(n_owners + 1, dtype=np.uint64)
+        _chk(lib().dnagpu_partition_kmers(self.h, dna.h, k, first, count, n_owners, C.byref(ptr),
+                                          offs.ctypes.data_as(u64p)))
+        return ptr.value, offs
+
+    def buffer_alloc(self, nbytes):
+        p = C.c_void_p()
+        _chk(lib().dnagpu_buffer_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def buffer_free(self, ptr):
+        lib().dnagpu_buffer_free(self.h, ptr)
+
+    # ---- batched operators
+    def kmer_hash(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty(max(k.size, 1), dtype=np.uint32)
+        _chk(lib().dnagpu_kmer_hash(self.h, k.ctypes.data, k.size, out.ctypes.data, 0))
+        return out[:k.size]
+
+    def kmer_match(self, keys, k, flt):
+        a = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty(max(a.size, 1), dtype=np.uint8)
+        _chk(lib().dnagpu_kmer_match(self.h, a.ctypes.data, a.size, k, C.byref(flt.c), out.ctypes.data, 0))
+        return out[:a.size].astype(bool)

@@ -1,0 +1,999 @@
+// dnagpu_api.hip -- the C-ABI of include/dnagpu.h over the gfx950 kernels.
+//
+// Host side only: argument checks in the reference's terms (same conditions, same message text as
+// the ereport() sites of dna.c), device buffer pool, the level loop of the count, event timing.
+// There is no CPU fallback: without a HIP device every entry point fails with DNAGPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/dnagpu.h"
+#include "kernels.hpp"
+
+using namespace dnagpu;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+static thread_local char g_err[512] = "";
+
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dnagpu_strerror(int status)
+{
+    switch (status) {
+    case DNAGPU_OK: return "ok";
+    case DNAGPU_ERR_INVALID_K: return "Invalid k value: must be between 1 and 32";             // dna.c:773
+    case DNAGPU_ERR_QKMER_LEN_MISMATCH: return "Qkmer pattern and kmer lengths do not match";   // dna.c:1107
+    case DNAGPU_ERR_PREFIX_TOO_LONG: return "Prefix length cannot exceed kmer length";         // dna.c:855
+    case DNAGPU_ERR_QKMER_INVALID: return "Invalid Qkmer sequence: must contain valid IUPAC nucleotide codes";  // dna.c:916
+    case DNAGPU_ERR_BAD_ARG: return "bad argument";
+    case DNAGPU_ERR_TOO_LARGE: return "too many k-mers for one call (limit 2^32 - 1)";
+    case DNAGPU_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required)";
+    case DNAGPU_ERR_OOM: return "out of memory";
+    case DNAGPU_ERR_HIP: return "HIP runtime or kernel failure";
+    case DNAGPU_ERR_INTERNAL: return "internal error";
+    }
+    return "unknown status";
+}
+
+extern "C" const char *dnagpu_last_error(void) { return g_err; }
+extern "C" int dnagpu_abi_version(void) { return DNAGPU_ABI_VERSION; }
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? DNAGPU_ERR_OOM : DNAGPU_ERR_HIP;              \
+        }                                                                                    \
+    } while (0)
+
+#define RC_TRY(expr)           \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != DNAGPU_OK)  \
+            return rc_;        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context + device buffer pool
+struct PoolBlock {
+    void *ptr;
+    size_t size;
+    bool in_use;
+};
+
+struct dnagpu_ctx {
+    int device;
+    hipStream_t stream;
+    std::vector<PoolBlock> pool;
+    bool profiling;
+    dnagpu_phase_times last_times;
+    // per-call event list (profiling)
+    std::vector<hipEvent_t> ev;
+    std::vector<const char *> ev_names;
+};
+
+struct dnagpu_dna {
+    u64 *words;
+    u64 n_words;
+    u64 n_bases;
+    bool owned;
+};
+
+struct dnagpu_hist {
+    u64 *keys;
+    u64 *counts;
+    u64 n_distinct;
+    u64 total;
+};
+
+static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes == 0)
+        bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); i++) {
+        PoolBlock &b = ctx->pool[i];
+        if (!b.in_use && b.size >= bytes && b.size <= bytes * 2 + (1u << 20))
+            if (best < 0 || b.size < ctx->pool[best].size)
+                best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].in_use = true;
+        *out = ctx->pool[best].ptr;
+        return DNAGPU_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // give pooled-but-idle memory back and retry once
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        for (size_t i = 0; i < ctx->pool.size();) {
+            if (!ctx->pool[i].in_use) {
+                hipFree(ctx->pool[i].ptr);
+                ctx->pool.erase(ctx->pool.begin() + i);
+            } else {
+                i++;
+            }
+        }
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_err("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return DNAGPU_ERR_OOM;
+    }
+    ctx->pool.push_back(PoolBlock{p, bytes, true});
+    *out = p;
+    return DNAGPU_OK;
+}
+
+// Buffers go back to the pool while kernels that use them may still be queued: every later user is
+// queued on the same stream, behind them.
+static void pool_free(dnagpu_ctx *ctx, void *p)
+{
+    if (!p)
+        return;
+    for (PoolBlock &b : ctx->pool)
+        if (b.ptr == p) {
+            b.in_use = false;
+            return;
+        }
+}
+
+template <typename T>
+static int pool_alloc_t(dnagpu_ctx *ctx, size_t n, T **out)
+{
+    void *p = nullptr;
+    int rc = pool_alloc(ctx, n * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+
+// frees a set of pool buffers at scope exit
+struct PoolScope {
+    dnagpu_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit PoolScope(dnagpu_ctx *c) : ctx(c) {}
+    ~PoolScope()
+    {
+        for (void *p : ptrs)
+            pool_free(ctx, p);
+    }
+    template <typename T>
+    int alloc(size_t n, T **out)
+    {
+        int rc = pool_alloc_t(ctx, n, out);
+        if (rc == DNAGPU_OK)
+            ptrs.push_back(*out);
+        return rc;
+    }
+    void release(void *p)   // hand ownership to the caller
+    {
+        ptrs.erase(std::remove(ptrs.begin(), ptrs.end(), p), ptrs.end());
+    }
+    void free_now(void *p)
+    {
+        release(p);
+        pool_free(ctx, p);
+    }
+};
+
+extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
+{
+    if (!out_ctx)
+        return DNAGPU_ERR_BAD_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_err("hipGetDeviceCount: %s (%d devices)", hipGetErrorString(e), n);
+        return DNAGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_err("device %d out of range (%d devices)", device, n);
+        return DNAGPU_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    dnagpu_ctx *ctx = new (std::nothrow) dnagpu_ctx();
+    if (!ctx)
+        return DNAGPU_ERR_OOM;
+    ctx->device = device;
+    ctx->profiling = false;
+    ctx->last_times.n = 0;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_err("hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return DNAGPU_ERR_HIP;
+    }
+    *out_ctx = ctx;
+    return DNAGPU_OK;
+}
+
+extern "C" void dnagpu_destroy(dnagpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (PoolBlock &b : ctx->pool)
+        hipFree(b.ptr);
+    for (hipEvent_t e : ctx->ev)
+        hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int dnagpu_synchronize(dnagpu_ctx *ctx)
+{
+    if (!ctx)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+extern "C" void *dnagpu_stream(dnagpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int dnagpu_trim(dnagpu_ctx *ctx)
+{
+    if (!ctx)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->pool.size();) {
+        if (!ctx->pool[i].in_use) {
+            hipFree(ctx->pool[i].ptr);
+            ctx->pool.erase(ctx->pool.begin() + i);
+        } else {
+            i++;
+        }
+    }
+    return DNAGPU_OK;
+}
+
+extern "C" uint64_t dnagpu_device_bytes(dnagpu_ctx *ctx)
+{
+    uint64_t t = 0;
+    if (ctx)
+        for (PoolBlock &b : ctx->pool)
+            t += b.size;
+    return t;
+}
+
+extern "C" int dnagpu_buffer_alloc(dnagpu_ctx *ctx, uint64_t bytes, void **dev_ptr)
+{
+    if (!ctx || !dev_ptr)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return pool_alloc(ctx, (size_t)bytes, dev_ptr);
+}
+
+extern "C" void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr)
+{
+    if (ctx)
+        pool_free(ctx, dev_ptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling helpers
+static void prof_begin(dnagpu_ctx *ctx)
+{
+    ctx->ev_names.clear();
+}
+
+static void prof_mark(dnagpu_ctx *ctx, const char *name)
+{
+    if (!ctx->profiling)
+        return;
+    size_t i = ctx->ev_names.size();
+    if (i >= ctx->ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess)
+            return;
+        ctx->ev.push_back(e);
+    }
+    hipEventRecord(ctx->ev[i], ctx->stream);
+    ctx->ev_names.push_back(name);
+}
+
+// names[i] labels the interval [mark i, mark i+1)
+static void prof_end(dnagpu_ctx *ctx)
+{
+    ctx->last_times.n = 0;
+    if (!ctx->profiling || ctx->ev_names.size() < 2)
+        return;
+    hipStreamSynchronize(ctx->stream);
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->ev_names.size() && n < DNAGPU_MAX_PHASES; i++) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
+        // merge intervals that carry the same label (levels beyond the table of names)
+        if (n > 0 && ctx->last_times.names[n - 1] == ctx->ev_names[i]) {
+            ctx->last_times.ms[n - 1] += ms;
+        } else {
+            ctx->last_times.names[n] = ctx->ev_names[i];
+            ctx->last_times.ms[n] = ms;
+            n++;
+        }
+    }
+    ctx->last_times.n = n;
+}
+
+extern "C" int dnagpu_last_phase_times(dnagpu_ctx *ctx, dnagpu_phase_times *out)
+{
+    if (!ctx || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    *out = ctx->last_times;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_set_profiling(dnagpu_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return DNAGPU_ERR_BAD_ARG;
+    ctx->profiling = enabled != 0;
+    return DNAGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dna
+static u64 words_for(u64 n_bases) { return (n_bases + 31) / 32; }
+
+extern "C" int dnagpu_dna_upload(dnagpu_ctx *ctx, const uint64_t *words, uint64_t n_bases, dnagpu_dna **out)
+{
+    if (!ctx || !out || (!words && n_bases))
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    u64 nw = words_for(n_bases);
+    u64 *d = nullptr;
+    RC_TRY(pool_alloc_t(ctx, (size_t)std::max<u64>(nw, 1), &d));
+    if (nw) {
+        hipError_t e = hipMemcpyAsync(d, words, nw * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            pool_free(ctx, d);
+            set_err("upload: %s", hipGetErrorString(e));
+            return DNAGPU_ERR_HIP;
+        }
+    }
+    dnagpu_dna *h = new (std::nothrow) dnagpu_dna{d, nw, n_bases, true};
+    if (!h) {
+        pool_free(ctx, d);
+        return DNAGPU_ERR_OOM;
+    }
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_wrap(dnagpu_ctx *ctx, const uint64_t *dev_words, uint64_t n_words,
+                               uint64_t n_bases, dnagpu_dna **out)
+{
+    if (!ctx || !out || (!dev_words && n_bases) || n_words < words_for(n_bases))
+        return DNAGPU_ERR_BAD_ARG;
+    dnagpu_dna *h = new (std::nothrow) dnagpu_dna{const_cast<u64 *>(dev_words), n_words, n_bases, false};
+    if (!h)
+        return DNAGPU_ERR_OOM;
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_synth(dnagpu_ctx *ctx, uint64_t seed, uint64_t n_bases, uint64_t motif_len,
+                                dnagpu_dna **out)
+{
+    if (!ctx || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    u64 nw = words_for(n_bases);
+    u64 *d = nullptr;
+    RC_TRY(pool_alloc_t(ctx, (size_t)std::max<u64>(nw, 1), &d));
+    hipError_t e = launch_synth(d, nw, n_bases, seed, motif_len, ctx->stream);
+    if (e != hipSuccess) {
+        pool_free(ctx, d);
+        set_err("synth: %s", hipGetErrorString(e));
+        return DNAGPU_ERR_HIP;
+    }
+    dnagpu_dna *h = new (std::nothrow) dnagpu_dna{d, nw, n_bases, true};
+    if (!h) {
+        pool_free(ctx, d);
+        return DNAGPU_ERR_OOM;
+    }
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t *words)
+{
+    if (!ctx || !dna || !words)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    u64 nw = words_for(dna->n_bases);
+    if (nw) {
+        HIP_TRY(hipMemcpyAsync(words, dna->words, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return DNAGPU_OK;
+}
+
+extern "C" uint64_t dnagpu_dna_length(const dnagpu_dna *dna) { return dna ? dna->n_bases : 0; }
+extern "C" const uint64_t *dnagpu_dna_device_words(const dnagpu_dna *dna) { return dna ? dna->words : nullptr; }
+
+extern "C" void dnagpu_dna_free(dnagpu_ctx *ctx, dnagpu_dna *dna)
+{
+    if (!dna)
+        return;
+    if (dna->owned && ctx)
+        pool_free(ctx, dna->words);
+    delete dna;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate_kmers
+extern "C" int dnagpu_kmer_count(uint64_t n_bases, int k, uint64_t *n_kmers)
+{
+    if (k <= 0 || k > 32)                      // dna.c:772
+        return DNAGPU_ERR_INVALID_K;
+    if (!n_kmers)
+        return DNAGPU_ERR_BAD_ARG;
+    *n_kmers = n_bases >= (u64)k ? n_bases - (u64)k + 1 : 0;   // dna.c:781 without the underflow
+    return DNAGPU_OK;
+}
+
+// validates [first, first+count) against the row count of generate_kmers(dna, k)
+static int check_range(const dnagpu_dna *dna, int k, u64 first, u64 count)
+{
+    u64 total = 0;
+    RC_TRY(dnagpu_kmer_count(dna->n_bases, k, &total));
+    if (first > total || count > total - first) {
+        set_err("rows [%llu, +%llu) outside generate_kmers' %llu rows", (unsigned long long)first,
+                (unsigned long long)count, (unsigned long long)total);
+        return DNAGPU_ERR_BAD_ARG;
+    }
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_generate_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                                     uint64_t count, uint64_t *out_keys, int out_on_device)
+{
+    if (!ctx || !dna)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    if (count == 0)
+        return DNAGPU_OK;
+    if (!out_keys)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (out_on_device) {
+        HIP_TRY(launch_extract(dna->words, dna->n_words, first, count, k, out_keys, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return DNAGPU_OK;
+    }
+    // host destination: batches through a device staging buffer, so a PostgreSQL caller can
+    // CHECK_FOR_INTERRUPTS between batches by asking for windows itself
+    PoolScope ps(ctx);
+    const u64 BATCH = (u64)1 << 26;            // 64 Mi keys = 512 MiB staging
+    u64 *stage = nullptr;
+    RC_TRY(ps.alloc((size_t)std::min(count, BATCH), &stage));
+    for (u64 done = 0; done < count; done += BATCH) {
+        u64 nb = std::min(BATCH, count - done);
+        HIP_TRY(launch_extract(dna->words, dna->n_words, first + done, nb, k, stage, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(out_keys + done, stage, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return DNAGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// filters: reference operator semantics -> FilterDev
+// IUPAC sets as 4-bit masks over codes (bit0 = A, bit1 = T, bit2 = C, bit3 = G), dna.c:1064-1081.
+static int iupac_set(char c)
+{
+    switch (c) {
+    case 'A': return 0x1;
+    case 'T': return 0x2;
+    case 'C': return 0x4;
+    case 'G': return 0x8;
+    case 'U': return 0x0;   // compares the decoded base with 'U': never true (dna.c:1070)
+    case 'W': return 0x3;
+    case 'S': return 0xC;
+    case 'M': return 0x5;
+    case 'K': return 0xA;
+    case 'R': return 0x9;
+    case 'Y': return 0x6;
+    case 'B': return 0xE;
+    case 'D': return 0xB;
+    case 'H': return 0x7;
+    case 'V': return 0xD;
+    case 'N': return 0xF;
+    }
+    return -1;
+}
+
+// has_rows: the reference raises operator errors only when the operator is actually evaluated
+static int build_filter(const dnagpu_filter *f, int k, bool has_rows, FilterDev *out)
+{
+    if (!f)
+        return DNAGPU_ERR_BAD_ARG;
+    FilterDev d;
+    memset(&d, 0, sizeof d);
+    switch (f->kind) {
+    case DNAGPU_FILTER_EQUALS:
+        // kmer_eq_internal: lengths must be equal, then bits (dna.c:655-668)
+        if (f->length != k) {
+            d.and_mask = 0;
+            d.eq_value = 1;                     // (key & 0) == 1: matches nothing
+        } else {
+            d.and_mask = ~(u64)0;
+            d.eq_value = f->bits;
+        }
+        break;
+    case DNAGPU_FILTER_STARTS_WITH:
+        if (f->length < 0)
+            return DNAGPU_ERR_BAD_ARG;
+        if (f->length > k) {                    // dna.c:854-856
+            if (has_rows)
+                return DNAGPU_ERR_PREFIX_TOO_LONG;
+            d.and_mask = 0;
+            d.eq_value = 1;
+            break;
+        }
+        d.and_mask = kmer_mask(f->length);      // dna.c:862, defined for length 32 too
+        if (f->length == 0)
+            d.and_mask = 0;
+        d.eq_value = f->bits;
+        break;
+    case DNAGPU_FILTER_CONTAINS: {
+        size_t len = strnlen(f->pattern, sizeof f->pattern);
+        if (len == 0 || len > 32)               // dna.c:877-886
+            return DNAGPU_ERR_QKMER_INVALID;
+        for (size_t i = 0; i < len; i++)
+            if (iupac_set(f->pattern[i]) < 0)   // dna.c:888-896
+                return DNAGPU_ERR_QKMER_INVALID;
+        if ((int)len != k) {                    // dna.c:1106-1108
+            if (has_rows)
+                return DNAGPU_ERR_QKMER_LEN_MISMATCH;
+            d.and_mask = 0;
+            d.eq_value = 1;
+            break;
+        }
+        d.use_planes = 1;
+        for (size_t i = 0; i < len; i++) {
+            int set = iupac_set(f->pattern[i]);
+            for (int c = 0; c < 4; c++)
+                if (!(set & (1 << c)))
+                    d.deny[c] |= (u64)1 << (2 * i);
+        }
+        break;
+    }
+    default:
+        return DNAGPU_ERR_BAD_ARG;
+    }
+    *out = d;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                                              const dnagpu_filter *filter, uint64_t first, uint64_t count,
+                                              uint64_t *out_keys, uint64_t *out_pos, uint64_t cap,
+                                              uint64_t *n_out, int out_on_device)
+{
+    if (!ctx || !dna || !n_out)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    FilterDev fd;
+    RC_TRY(build_filter(filter, k, count > 0, &fd));
+    *n_out = 0;
+    if (count == 0)
+        return DNAGPU_OK;
+    if (count > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    const u64 n_tiles = (count + FILTER_TILE - 1) / FILTER_TILE;
+    u32 *tile_counts = nullptr, *scan_tmp = nullptr, *total_d = nullptr;
+    RC_TRY(ps.alloc((size_t)n_tiles, &tile_counts));
+    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_tiles), &scan_tmp));
+    RC_TRY(ps.alloc(4, &total_d));
+    HIP_TRY(launch_filter_count(dna->words, dna->n_words, first, count, k, fd, tile_counts, ctx->stream));
+    HIP_TRY(launch_scan_u32(tile_counts, tile_counts, n_tiles, scan_tmp, total_d, ctx->stream));
+    u32 total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, total_d, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    u64 nwrite = std::min<u64>(total, cap);
+    if (nwrite == 0 || (!out_keys && !out_pos))
+        return DNAGPU_OK;
+    u64 *dk = nullptr, *dp = nullptr;
+    if (out_on_device) {
+        dk = out_keys;
+        dp = out_pos;
+    } else {
+        if (out_keys)
+            RC_TRY(ps.alloc((size_t)nwrite, &dk));
+        if (out_pos)
+            RC_TRY(ps.alloc((size_t)nwrite, &dp));
+    }
+    HIP_TRY(launch_filter_write(dna->words, dna->n_words, first, count, k, fd, tile_counts, dk, dp, nwrite,
+                                ctx->stream));
+    if (!out_on_device) {
+        if (out_keys)
+            HIP_TRY(hipMemcpyAsync(out_keys, dk, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_pos)
+            HIP_TRY(hipMemcpyAsync(out_pos, dp, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched operators
+extern "C" int dnagpu_kmer_hash(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, uint32_t *out, int on_device)
+{
+    if (!ctx || (n && (!keys || !out)))
+        return DNAGPU_ERR_BAD_ARG;
+    if (n == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (on_device) {
+        HIP_TRY(launch_hash_batch(keys, n, out, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return DNAGPU_OK;
+    }
+    PoolScope ps(ctx);
+    u64 *dk = nullptr;
+    u32 *dh = nullptr;
+    RC_TRY(ps.alloc((size_t)n, &dk));
+    RC_TRY(ps.alloc((size_t)n, &dh));
+    HIP_TRY(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_hash_batch(dk, n, dh, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, dh, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
+                                 const dnagpu_filter *filter, uint8_t *flags, int on_device)
+{
+    if (!ctx || (n && (!keys || !flags)))
+        return DNAGPU_ERR_BAD_ARG;
+    if (k <= 0 || k > 32)
+        return DNAGPU_ERR_INVALID_K;
+    FilterDev fd;
+    RC_TRY(build_filter(filter, k, n > 0, &fd));
+    if (n == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (on_device) {
+        HIP_TRY(launch_match_batch(keys, n, fd, flags, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return DNAGPU_OK;
+    }
+    PoolScope ps(ctx);
+    u64 *dk = nullptr;
+    uint8_t *df = nullptr;
+    RC_TRY(ps.alloc((size_t)n, &dk));
+    RC_TRY(ps.alloc((size_t)n, &df));
+    HIP_TRY(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_match_batch(dk, n, fd, df, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(flags, df, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GROUP BY kmer, count(*): the level loop
+static const char *const LEVEL_HIST_NAMES[] = {"level0_hist", "level1_hist", "level2_hist", "level3_hist", "levelN_hist"};
+static const char *const LEVEL_PREFIX_NAMES[] = {"level0_prefix", "level1_prefix", "level2_prefix", "level3_prefix", "levelN_prefix"};
+static const char *const LEVEL_SCATTER_NAMES[] = {"level0_scatter", "level1_scatter", "level2_scatter", "level3_scatter", "levelN_scatter"};
+static const char *const LEVEL_PLAN_NAMES[] = {"level0_plan", "level1_plan", "level2_plan", "level3_plan", "levelN_plan"};
+
+struct TreeResult {
+    Node *nodes;      // final node list (leaves, or the children of a forced level)
+    u32 n_nodes;
+    u64 *buf0;
+    u64 *buf1;        // may be null if never needed
+};
+
+// Runs levels until every node is a leaf (force_bits == 0), or exactly one forced level of
+// `force_bits` bits on the root (force_bits > 0).  dna != null: root over the packed sequence
+// (keys land in buf0, allocated here); else root over keys_in (used as buf0).
+static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k,
+                    u64 *keys_in, int force_bits, TreeResult *res)
+{
+    hipStream_t st = ctx->stream;
+    u64 *buf0 = keys_in, *buf1 = nullptr;
+    Node root;
+    memset(&root, 0, sizeof root);
+    root.start = 0;
+    root.len = (u32)n;
+    root.meta = (u32)(2 * k);
+    bool src_dna = false;
+    if (dna) {
+        RC_TRY(ps.alloc((size_t)n, &buf0));
+        if (n <= (u64)LEAF_CAP && force_bits == 0) {
+            HIP_TRY(launch_extract(dna->words, dna->n_words, first, n, k, buf0, st));
+        } else {
+            src_dna = true;
+            root.meta |= NODE_BUF;          // children of the dna root go to buffer 0
+        }
+    }
+    Node *cur = nullptr;
+    RC_TRY(ps.alloc(1, &cur));
+    HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
+    u32 n_nodes = 1;
+
+    u32 chunk_len = (u32)std::max<u64>(4 * (u64)scatter_tile_keys(), (n + 4095) / 4096);
+    chunk_len = (chunk_len + scatter_tile_keys() - 1) / scatter_tile_keys() * scatter_tile_keys();
+
+    for (int level = 0;; level++) {
+        const int li = std::min(level, 4);
+        prof_mark(ctx, LEVEL_PLAN_NAMES[li]);
+        u32 *outc = nullptr, *nch = nullptr, *scan_tmp = nullptr;
+        LevelCounters *ctr = nullptr;
+        RC_TRY(ps.alloc(n_nodes, &outc));
+        RC_TRY(ps.alloc(n_nodes, &nch));
+        RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
+        RC_TRY(ps.alloc(1, &ctr));
+        HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(LevelCounters), st));
+        HIP_TRY(launch_plan(cur, n_nodes, force_bits > 0 ? -force_bits : level, chunk_len, outc, nch, ctr, st));
+        HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
+        HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
+        LevelCounters hc;
+        HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hc.n_split == 0) {
+            ps.free_now(outc);
+            ps.free_now(nch);
+            ps.free_now(scan_tmp);
+            ps.free_now(ctr);
+            break;
+        }
+        Chunk *chunks = nullptr;
+        u32 *hist = nullptr, *tot = nullptr;
+        Node *next = nullptr;
+        RC_TRY(ps.alloc(hc.n_chunks, &chunks));
+        RC_TRY(ps.alloc((size_t)hc.n_chunks * ROW_STRIDE, &hist));
+        RC_TRY(ps.alloc((size_t)hc.n_chunks * ROW_STRIDE, &tot));
+        RC_TRY(ps.alloc(hc.n_next, &next));
+        HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, chunks, st));
+        prof_mark(ctx, LEVEL_HIST_NAMES[li]);
+        HIP_TRY(launch_level_hist(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
+                                  dna ? dna->n_words : 0, first, k, buf0, buf1, hist, st));
+        prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
+        HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, chunk_len, hist, tot, st));
+        HIP_TRY(launch_level_children(cur, n_nodes, tot, next, st));
+        if (hc.n_scatter) {
+            if (!src_dna && !buf1)
+                RC_TRY(ps.alloc((size_t)n, &buf1));
+            prof_mark(ctx, LEVEL_SCATTER_NAMES[li]);
+            HIP_TRY(launch_level_scatter(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
+                                         dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot, st));
+        }
+        ps.free_now(outc);
+        ps.free_now(nch);
+        ps.free_now(scan_tmp);
+        ps.free_now(ctr);
+        ps.free_now(chunks);
+        ps.free_now(hist);
+        ps.free_now(tot);
+        ps.free_now(cur);
+        cur = next;
+        n_nodes = hc.n_next;
+        src_dna = false;
+        if (force_bits > 0)
+            break;
+    }
+    res->nodes = cur;
+    res->n_nodes = n_nodes;
+    res->buf0 = buf0;
+    res->buf1 = buf1;
+    return DNAGPU_OK;
+}
+
+static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
+                      dnagpu_hist **out)
+{
+    if (n > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, n};
+    if (!h)
+        return DNAGPU_ERR_OOM;
+    if (n == 0) {
+        *out = h;
+        return DNAGPU_OK;
+    }
+    prof_begin(ctx);
+    int rc;
+    {
+        PoolScope ps(ctx);
+        TreeResult tr;
+        rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr);
+        u64 *status = nullptr;
+        u32 *ticket = nullptr;
+        u64 *ok = nullptr, *oc = nullptr;
+        // a k-mer of k bases has at most 4^k distinct values
+        u64 cap = n;
+        if (k < 16)
+            cap = std::min<u64>(n, (u64)1 << (2 * k));
+        if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &status);
+        if (rc == DNAGPU_OK) rc = ps.alloc(2, &ticket);
+        if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
+        if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
+        hipError_t e = hipSuccess;
+        u64 last = 0;
+        u32 tick[2] = {0, 0};
+        if (rc == DNAGPU_OK) {
+            prof_mark(ctx, "leaves");
+            e = hipMemsetAsync(status, 0, (size_t)tr.n_nodes * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(ticket, 0, 8, ctx->stream);
+            if (e == hipSuccess)
+                e = launch_leaves(tr.nodes, tr.n_nodes, tr.buf0, tr.buf1, status, ticket, ok, oc, ctx->stream);
+            prof_mark(ctx, "end");
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(&last, status + (tr.n_nodes - 1), 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(tick, ticket, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                set_err("leaves: %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            } else if (tick[1] != 0) {
+                set_err("leaves: chained scan timed out");
+                rc = DNAGPU_ERR_INTERNAL;
+            }
+        }
+        if (rc == DNAGPU_OK) {
+            h->n_distinct = last & (((u64)1 << 62) - 1);
+            h->keys = ok;
+            h->counts = oc;
+            ps.release(ok);
+            ps.release(oc);
+        }
+    }
+    prof_end(ctx);
+    if (rc != DNAGPU_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                                  uint64_t count, dnagpu_hist **out)
+{
+    if (!ctx || !dna || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    HIP_TRY(hipSetDevice(ctx->device));
+    return count_core(ctx, dna, first, count, k, nullptr, out);
+}
+
+extern "C" int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out)
+{
+    if (!ctx || !out || (n && !dev_keys))
+        return DNAGPU_ERR_BAD_ARG;
+    if (k <= 0 || k > 32)
+        return DNAGPU_ERR_INVALID_K;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return count_core(ctx, nullptr, 0, n, k, dev_keys, out);
+}
+
+extern "C" uint64_t dnagpu_hist_distinct(const dnagpu_hist *h) { return h ? h->n_distinct : 0; }
+extern "C" uint64_t dnagpu_hist_total(const dnagpu_hist *h) { return h ? h->total : 0; }
+extern "C" const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h) { return h ? h->keys : nullptr; }
+extern "C" const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
+
+extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
+                                    uint64_t *keys, uint64_t *counts)
+{
+    if (!ctx || !h)
+        return DNAGPU_ERR_BAD_ARG;
+    if (first > h->n_distinct || count > h->n_distinct - first)
+        return DNAGPU_ERR_BAD_ARG;
+    if (count == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (keys)
+        HIP_TRY(hipMemcpyAsync(keys, h->keys + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts)
+        HIP_TRY(hipMemcpyAsync(counts, h->counts + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t *total, uint64_t *unique,
+                                   uint64_t *checksum)
+{
+    if (!ctx || !h)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    u64 *res = nullptr;
+    RC_TRY(ps.alloc(4, &res));
+    HIP_TRY(hipMemsetAsync(res, 0, 32, ctx->stream));
+    HIP_TRY(launch_hist_summary(h->keys, h->counts, h->n_distinct, res, ctx->stream));
+    u64 r[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(r, res, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total) *total = r[0];
+    if (unique) *unique = r[1];
+    if (checksum) *checksum = r[2];
+    return DNAGPU_OK;
+}
+
+extern "C" void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h)
+{
+    if (!h)
+        return;
+    if (ctx) {
+        pool_free(ctx, h->keys);
+        pool_free(ctx, h->counts);
+    }
+    delete h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU step 1: one forced level over the dna root, children grouped by owner
+extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                                      uint64_t count, int n_owners, uint64_t **dev_keys,
+                                      uint64_t *owner_offsets)
+{
+    if (!ctx || !dna || !dev_keys || !owner_offsets || n_owners < 1 || n_owners > (1 << MAX_SPLIT_BITS))
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    if (count > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    *dev_keys = nullptr;
+    for (int o = 0; o <= n_owners; o++)
+        owner_offsets[o] = 0;
+    if (count == 0)
+        return DNAGPU_OK;
+    const int bits = std::min(2 * k, MAX_SPLIT_BITS);
+    const u32 R = 1u << bits;
+    prof_begin(ctx);
+    PoolScope ps(ctx);
+    TreeResult tr;
+    RC_TRY(run_tree(ctx, ps, dna, first, count, k, nullptr, bits, &tr));
+    if (tr.n_nodes != R) {
+        set_err("partition: expected %u children, got %u", R, tr.n_nodes);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    std::vector<Node> kids(R);
+    HIP_TRY(hipMemcpyAsync(kids.data(), tr.nodes, (size_t)R * sizeof(Node), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // owner o owns digits d with (d * n_owners) >> bits == o: first digit = ceil(o * R / n_owners)
+    for (int o = 0; o <= n_owners; o++) {
+        u64 d0 = ((u64)o * R + n_owners - 1) / n_owners;
+        owner_offsets[o] = d0 >= R ? count : kids[d0].start;
+    }
+    if (2 * k == bits) {
+        // terminal level: nothing was scattered (children carry key = prefix, count = len); expand
+        // is not needed by any caller today: k <= 5 counts run on one GPU
+        set_err("partition: k too small to shard (2k <= %d bits)", MAX_SPLIT_BITS);
+        return DNAGPU_ERR_BAD_ARG;
+    }
+    ps.release(tr.buf0);
+    *dev_keys = tr.buf0;
+    prof_end(ctx);
+    return DNAGPU_OK;
+}

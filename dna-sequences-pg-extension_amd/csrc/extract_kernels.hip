@@ -1,0 +1,406 @@
+// extract_kernels.hip -- generate_kmers and its fused WHERE operators on gfx950.
+//
+// All of these are HBM-bound integer kernels: 0.25 B of packed input per k-mer against 8 B (or,
+// filtered, 8-16 B per match) of output.  The packed words a wave needs for 128 consecutive
+// positions are 4-5 words, so the input side is served by L1 broadcasts; the design target is the
+// store side: every wave-instruction writes 1 KiB of consecutive keys (16 B per lane).
+#include "kernels.hpp"
+
+namespace dnagpu {
+
+// ------------------------------------------------------------------------------------------------
+// synthetic packed dna: word w = splitmix64(seed + w); repeat variant tiles the first motif_len
+// bases over the second half.  Mirrors oracle/kmer_oracle.c orc_synth_words{,_repeat}.
+__global__ __launch_bounds__(256) void synth_kernel(u64 *__restrict__ words, u64 n_words, u64 n_bases,
+                                                    u64 seed, u64 motif_len)
+{
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words)
+        return;
+    u64 v;
+    u64 half = n_bases / 2;
+    if (motif_len == 0 || (w + 1) * 32 <= half) {
+        v = splitmix64(seed + w);
+    } else {
+        v = 0;
+        for (unsigned j = 0; j < 32; j++) {
+            u64 i = w * 32 + j;
+            if (i >= n_bases)
+                break;
+            u64 src = i < half ? i : (i - half) % motif_len;
+            v |= ((splitmix64(seed + (src >> 5)) >> ((src & 31) * 2)) & 3) << (2 * j);
+        }
+    }
+    u64 end = (w + 1) * 32;
+    if (end > n_bases) {
+        unsigned tail = (unsigned)(n_bases - w * 32);   // 1..31 valid bases in the last word
+        v &= (((u64)1 << (2 * tail)) - 1);
+    }
+    words[w] = v;
+}
+
+hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s)
+{
+    if (n_words == 0)
+        return hipSuccess;
+    unsigned grid = (unsigned)((n_words + 255) / 256);
+    hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(256), 0, s, words, n_words, n_bases, seed, motif_len);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate_kmers rows [first, first+count) -> out_keys[0..count)  (dna.c:803-825 per row)
+// One workgroup = 4096 consecutive rows; lane l of each wave-instruction stores rows 2l, 2l+1 of
+// a 128-row group as one 16-byte store: 1 KiB contiguous per wave-instruction.
+constexpr int EXTRACT_TILE = 4096;
+
+__global__ __launch_bounds__(256) void extract_kernel(const u64 *__restrict__ words, u64 n_words, u64 first,
+                                                      u64 count, u64 mask, u64 *__restrict__ out)
+{
+    const u64 base = (u64)blockIdx.x * EXTRACT_TILE;
+    const bool aligned = (((uintptr_t)out) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < EXTRACT_TILE / 512; j++) {
+        u64 i = base + (u64)j * 512 + 2 * threadIdx.x;
+        if (i >= count)
+            break;
+        u64 k0 = key_at(words, n_words, first + i, mask);
+        if (i + 1 < count) {
+            u64 k1 = key_at(words, n_words, first + i + 1, mask);
+            if (aligned) {
+                ulonglong2 v;
+                v.x = k0;
+                v.y = k1;
+                *reinterpret_cast<ulonglong2 *>(out + i) = v;
+            } else {
+                out[i] = k0;
+                out[i + 1] = k1;
+            }
+        } else {
+            out[i] = k0;
+        }
+    }
+}
+
+hipError_t launch_extract(const u64 *words, u64 n_words, u64 first, u64 count, int k, u64 *out_keys,
+                          hipStream_t s)
+{
+    if (count == 0)
+        return hipSuccess;
+    unsigned grid = (unsigned)((count + EXTRACT_TILE - 1) / EXTRACT_TILE);
+    hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(256), 0, s, words, n_words, first, count,
+                       kmer_mask(k), out_keys);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate_kmers + WHERE: tile t covers rows [t*4096, (t+1)*4096).  Inside a tile, row r is handled
+// by thread r % 256 in iteration r / 256, so a wave's ballot is in row order and a (iteration, wave)
+// table of popcounts gives every match its position-ordered slot without sorting.
+
+__global__ __launch_bounds__(256) void filter_count_kernel(const u64 *__restrict__ words, u64 n_words,
+                                                           u64 first, u64 count, u64 mask, FilterDev f,
+                                                           u32 *__restrict__ tile_counts)
+{
+    __shared__ u32 wsum[4];
+    const u64 base = (u64)blockIdx.x * FILTER_TILE;
+    u32 c = 0;
+#pragma unroll 4
+    for (int j = 0; j < FILTER_TILE / 256; j++) {
+        u64 i = base + (u64)j * 256 + threadIdx.x;
+        if (i < count)
+            c += filter_match(f, key_at(words, n_words, first + i, mask)) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+hipError_t launch_filter_count(const u64 *words, u64 n_words, u64 first, u64 count, int k,
+                               const FilterDev &f, u32 *tile_counts, hipStream_t s)
+{
+    if (count == 0)
+        return hipSuccess;
+    unsigned grid = (unsigned)((count + FILTER_TILE - 1) / FILTER_TILE);
+    hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(256), 0, s, words, n_words, first, count,
+                       kmer_mask(k), f, tile_counts);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void filter_write_kernel(const u64 *__restrict__ words, u64 n_words,
+                                                           u64 first, u64 count, u64 mask, FilterDev f,
+                                                           const u32 *__restrict__ tile_offsets,
+                                                           u64 *__restrict__ out_keys,
+                                                           u64 *__restrict__ out_pos, u64 cap)
+{
+    constexpr int ITER = FILTER_TILE / 256;          // 16
+    __shared__ u32 cnt[ITER * 4];                    // [iteration][wave] popcounts -> exclusive offsets
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * FILTER_TILE;
+    u64 keys[ITER];
+    u64 ballots[ITER];
+#pragma unroll
+    for (int j = 0; j < ITER; j++) {
+        u64 i = base + (u64)j * 256 + threadIdx.x;
+        bool m = false;
+        keys[j] = 0;
+        if (i < count) {
+            keys[j] = key_at(words, n_words, first + i, mask);
+            m = filter_match(f, keys[j]);
+        }
+        ballots[j] = __ballot(m);
+        if (lane == 0)
+            cnt[j * 4 + wave] = (u32)__popcll(ballots[j]);
+    }
+    __syncthreads();
+    if (wave == 0) {                                 // 64 table entries: one wave scans them
+        u32 v = cnt[lane], inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 t = __shfl_up(inc, off);
+            if (lane >= off)
+                inc += t;
+        }
+        cnt[lane] = inc - v;
+    }
+    __syncthreads();
+    const u64 tile_off = tile_offsets[blockIdx.x];
+    const u64 below = ((u64)1 << lane) - 1;
+#pragma unroll
+    for (int j = 0; j < ITER; j++) {
+        if ((ballots[j] >> lane) & 1) {
+            u64 idx = tile_off + cnt[j * 4 + wave] + (u64)__popcll(ballots[j] & below);
+            if (idx < cap) {
+                if (out_keys)
+                    out_keys[idx] = keys[j];
+                if (out_pos)
+                    out_pos[idx] = first + base + (u64)j * 256 + threadIdx.x;
+            }
+        }
+    }
+}
+
+hipError_t launch_filter_write(const u64 *words, u64 n_words, u64 first, u64 count, int k,
+                               const FilterDev &f, const u32 *tile_offsets, u64 *out_keys,
+                               u64 *out_pos, u64 cap, hipStream_t s)
+{
+    if (count == 0)
+        return hipSuccess;
+    unsigned grid = (unsigned)((count + FILTER_TILE - 1) / FILTER_TILE);
+    hipLaunchKernelGGL(filter_write_kernel, dim3(grid), dim3(256), 0, s, words, n_words, first, count,
+                       kmer_mask(k), f, tile_offsets, out_keys, out_pos, cap);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched operators over key arrays
+
+__global__ __launch_bounds__(256) void hash_batch_kernel(const u64 *__restrict__ keys, u64 n,
+                                                         u32 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = pg_kmer_hash(keys[i]);
+}
+
+hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    u64 blocks = (n + 255) / 256;
+    unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(hash_batch_kernel, dim3(grid), dim3(256), 0, s, keys, n, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void match_batch_kernel(const u64 *__restrict__ keys, u64 n, FilterDev f,
+                                                          uint8_t *__restrict__ flags)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        flags[i] = filter_match(f, keys[i]) ? 1 : 0;
+}
+
+hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_t *flags, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    u64 blocks = (n + 255) / 256;
+    unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(match_batch_kernel, dim3(grid), dim3(256), 0, s, keys, n, f, flags);
+    return hipGetLastError();
+}
+
+// sum(count), #(count == 1), wrapping sum of pair digests: three wave reductions + 3 atomics per block
+__global__ __launch_bounds__(256) void hist_summary_kernel(const u64 *__restrict__ keys,
+                                                           const u64 *__restrict__ counts, u64 n,
+                                                           u64 *__restrict__ result)
+{
+    __shared__ u64 part[3][4];
+    u64 t = 0, u = 0, c = 0;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        u64 cnt = counts[i];
+        t += cnt;
+        u += cnt == 1;
+        c += pair_mix(keys[i], cnt);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        t += __shfl_down(t, off);
+        u += __shfl_down(u, off);
+        c += __shfl_down(c, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = t;
+        part[1][threadIdx.x >> 6] = u;
+        part[2][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        u64 v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        atomicAdd(reinterpret_cast<unsigned long long *>(result + threadIdx.x), (unsigned long long)v);
+    }
+}
+
+hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *result3, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    u64 blocks = (n + 255) / 256;
+    unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(hist_summary_kernel, dim3(grid), dim3(256), 0, s, keys, counts, n, result3);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of u32 arrays (tile offsets, node lists): reduce -> scan of block sums -> apply.
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;   // 2048 values per workgroup
+
+u64 scan_tmp_words(u64 n)
+{
+    return (n + SCAN_TILE - 1) / SCAN_TILE + 1;
+}
+
+__device__ __forceinline__ u32 block_reduce_256(u32 v, u32 *sh4)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0)
+        sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const u32 *__restrict__ in, u64 n,
+                                                                 u32 *__restrict__ sums)
+{
+    __shared__ u32 sh4[4];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++)
+        if (base + q < n)
+            v += in[base + q];
+    u32 r = block_reduce_256(v, sh4);
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = r;
+}
+
+// one workgroup scans the block sums in place (exclusive) and stores the grand total
+__global__ __launch_bounds__(1024) void scan_sums_kernel(u32 *__restrict__ sums, u64 nb, u32 *__restrict__ total)
+{
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_sh = 0;
+    __syncthreads();
+    for (u64 b0 = 0; b0 < nb; b0 += 1024) {
+        u64 i = b0 + threadIdx.x;
+        u32 v = i < nb ? sums[i] : 0, inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 t = __shfl_up(inc, off);
+            if (lane >= off)
+                inc += t;
+        }
+        if (lane == 63)
+            wtot[wave] = inc;
+        __syncthreads();
+        u32 wbase = 0, all = 0;
+        for (int w = 0; w < 16; w++) {
+            u32 t = wtot[w];
+            if (w < wave)
+                wbase += t;
+            all += t;
+        }
+        u32 carry = carry_sh;
+        if (i < nb)
+            sums[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry_sh = carry + all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total)
+        *total = carry_sh;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const u32 *__restrict__ in, u32 *__restrict__ out,
+                                                                u64 n, const u32 *__restrict__ sums)
+{
+    __shared__ u32 wtot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        v[q] = (base + q < n) ? in[base + q] : 0;
+        sum += v[q];
+    }
+    u32 inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(inc, off);
+        if (lane >= off)
+            inc += t;
+    }
+    if (lane == 63)
+        wtot[wave] = inc;
+    __syncthreads();
+    u32 wbase = 0;
+    for (int w = 0; w < wave; w++)
+        wbase += wtot[w];
+    u32 run = sums[blockIdx.x] + wbase + inc - sum;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        if (base + q < n)
+            out[base + q] = run;
+        run += v[q];
+    }
+}
+
+hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total, hipStream_t s)
+{
+    if (n == 0) {
+        if (total)
+            return hipMemsetAsync(total, 0, sizeof(u32), s);
+        return hipSuccess;
+    }
+    u64 nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, in, n, tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, tmp, nb, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, in, out, n, tmp);
+    return hipGetLastError();
+}
+
+}  // namespace dnagpu

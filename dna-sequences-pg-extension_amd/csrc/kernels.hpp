@@ -1,0 +1,97 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (internal; the public surface is
+// include/dnagpu.h).  Every launcher enqueues on `stream` and returns hipGetLastError().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmer_device.hpp"
+
+namespace dnagpu {
+
+// ---------------------------------------------------------------- extract_kernels.hip
+hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s);
+hipError_t launch_extract(const u64 *words, u64 n_words, u64 first, u64 count, int k, u64 *out_keys,
+                          hipStream_t s);
+
+// position-ordered filtered extraction, two sweeps over the (tiny) packed input:
+//   count sweep -> per-tile match counts; exclusive scan; write sweep -> compacted keys/positions
+constexpr int FILTER_TILE = 4096;
+hipError_t launch_filter_count(const u64 *words, u64 n_words, u64 first, u64 count, int k,
+                               const FilterDev &f, u32 *tile_counts, hipStream_t s);
+hipError_t launch_filter_write(const u64 *words, u64 n_words, u64 first, u64 count, int k,
+                               const FilterDev &f, const u32 *tile_offsets, u64 *out_keys,
+                               u64 *out_pos, u64 cap, hipStream_t s);
+
+hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s);
+hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_t *flags, hipStream_t s);
+// result[0] += sum(count), result[1] += #(count == 1), result[2] += sum(pair_mix); zero it first
+hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *result3, hipStream_t s);
+
+// exclusive scan of n u32 values (in != out allowed, in == out allowed); *total receives the sum.
+// tmp must hold scan_tmp_words(n) u32 values.
+u64 scan_tmp_words(u64 n);
+hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total, hipStream_t s);
+
+// ---------------------------------------------------------------- count_kernels.hip
+// MSD radix tree over the keys (DESIGN.md "count"): every level splits the oversize nodes on their
+// next most significant bits; leaves (<= LEAF_CAP keys, or no bits left) are sorted and run-length
+// encoded in LDS, in key order, with a chained scan giving each leaf its output offset.
+constexpr int LEAF_CAP = 4096;        // max keys a leaf workgroup sorts in LDS
+constexpr int LEAF_TARGET = 2048;     // planned mean leaf size
+constexpr int MAX_SPLIT_BITS = 10;    // widest digit of one level (1024 children)
+constexpr int ROW_STRIDE = 1 << MAX_SPLIT_BITS;
+
+struct Node {           // 32 bytes
+    u32 start;          // index of the node's first key in its buffer (root over dna: 0)
+    u32 len;            // keys in the node
+    u32 meta;           // bits 0-7: remaining (not yet fixed) key bits; bit 8: buffer; bit 9: terminal
+    u32 split;          // plan: digit width this level (0 = leaf)
+    u64 prefix;         // the fixed high bits of every key in the node (low `rem` bits zero)
+    u32 child_base;     // plan: index of the first child (or of the node itself) in the next list
+    u32 chunk_base;     // plan: index of the node's first chunk
+};
+constexpr u32 NODE_BUF = 1u << 8;
+constexpr u32 NODE_TERMINAL = 1u << 9;
+
+struct Chunk {          // 16 bytes: a contiguous piece of one node, the unit of work of a level
+    u32 node;
+    u32 off;            // offset inside the node
+    u32 len;
+    u32 pad;
+};
+
+struct LevelCounters {  // read back by the host once per level
+    u32 n_next;         // nodes in the next list
+    u32 n_chunks;
+    u32 n_split;        // nodes being split this level
+    u32 n_scatter;      // of which non-terminal (their keys move)
+};
+
+hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
+                       LevelCounters *ctr, hipStream_t s);
+hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, const u32 *child_base,
+                              const u32 *chunk_base, Node *nodes_rw, Chunk *chunks, hipStream_t s);
+// src_dna != 0: the (single) node being split is the root over the packed sequence
+hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
+                             const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
+                             const u64 *buf1, u32 *hist, hipStream_t s);
+// per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
+// into tot[row of the node's first chunk]
+hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 chunk_len,
+                               u32 *hist, u32 *tot, hipStream_t s);
+// per node: leaf -> copied to the next list; split -> totals scanned over digits, children appended
+// in digit (= key) order, tot row overwritten with each digit's absolute base
+hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *tot, Node *next, hipStream_t s);
+hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
+                                const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
+                                const u32 *hist, const u32 *tot, hipStream_t s);
+// leaves -> (key, count) groups in key order.  status: n_leaves u64 zeroed; ticket: two u32 zeroed
+// (ticket[0] = next leaf to take, ticket[1] = error flag set if the chained scan gave up waiting).
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
+                         u64 *status, u32 *ticket, u64 *out_keys, u64 *out_counts, hipStream_t s);
+
+// scatter-only microbenchmark entry (bench tooling): one level over a key array
+int scatter_tile_keys();
+int scatter_threads();
+
+}  // namespace dnagpu

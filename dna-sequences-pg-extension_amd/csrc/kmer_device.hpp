@@ -1,0 +1,104 @@
+// kmer_device.hpp -- device-side bit arithmetic shared by every kernel (gfx950 only).
+//
+// Formats are the reference's: packed dna = uint64 words, base i at bits (2i mod 64) of word i/32
+// (dna.c:114-128); kmer key = uint64 with base i at bits 2i..2i+1 (dna.c:397-420).  The k-mer at
+// position p is therefore bits [2p, 2p+2k) of the word stream: no per-base loop is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dnagpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+__host__ __device__ __forceinline__ u64 kmer_mask(int k)
+{
+    return k >= 32 ? ~(u64)0 : (((u64)1 << (2 * k)) - 1);
+}
+
+// bits [sh, sh+64) of the 128-bit value hi:lo, sh in 0..62
+__device__ __forceinline__ u64 funnel(u64 lo, u64 hi, unsigned sh)
+{
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+
+// key of the k-mer starting at base `pos` (masked); words[n_words] is never read
+__device__ __forceinline__ u64 key_at(const u64 *__restrict__ words, u64 n_words, u64 pos, u64 mask)
+{
+    u64 w = pos >> 5;
+    unsigned sh = (unsigned)(pos & 31) * 2;
+    u64 lo = words[w];
+    u64 hi = (w + 1 < n_words) ? words[w + 1] : 0;
+    return funnel(lo, hi, sh) & mask;
+}
+
+__host__ __device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// kmer_hash (dna.c:722-735) = PostgreSQL hash_any over the 8 key bytes: lookup3 final() with
+// a = b = c = 0x9e3779b9 + 8 + 3923095, b += high word, a += low word.
+__host__ __device__ __forceinline__ u32 rot32(u32 x, int k) { return (x << k) | (x >> (32 - k)); }
+__host__ __device__ __forceinline__ u32 pg_kmer_hash(u64 bits)
+{
+    u32 a, b, c;
+    a = b = c = 0x9e3779b9u + 8u + 3923095u;
+    b += (u32)(bits >> 32);
+    a += (u32)bits;
+    c ^= b; c -= rot32(b, 14);
+    a ^= c; a -= rot32(c, 11);
+    b ^= a; b -= rot32(a, 25);
+    c ^= b; c -= rot32(b, 16);
+    a ^= c; a -= rot32(c, 4);
+    b ^= a; b -= rot32(a, 14);
+    c ^= b; c -= rot32(b, 24);
+    return c;
+}
+
+// order-independent digest of one (key, count) group; mirrored by the oracle's orc_pair_mix
+__host__ __device__ __forceinline__ u64 pair_mix(u64 key, u64 count)
+{
+    u64 x = splitmix64(key ^ 0x6a09e667f3bcc909ull);
+    return x * (2 * count + 1) + splitmix64(count);
+}
+
+// ---- WHERE operators as branch-free bit tests -----------------------------------------------
+// One descriptor covers `=`, `^@` and `@>`:
+//   masked compare  (key & and_mask) == eq_value          kmer_eq / starts_with (dna.c:655-668, 862-863)
+//   IUPAC planes    deny[c] has bit 2i set when code c is NOT in the pattern's set at position i
+//                   (nucleotide_matches, dna.c:1064-1086; 'U' denies all four codes)
+struct FilterDev {
+    u64 and_mask;
+    u64 eq_value;
+    u64 deny[4];   // indexed by 2-bit code: A=0 T=1 C=2 G=3
+    int use_planes;
+};
+
+__device__ __forceinline__ bool filter_match(const FilterDev &f, u64 key)
+{
+    if (!f.use_planes)
+        return (key & f.and_mask) == f.eq_value;
+    const u64 EVEN = 0x5555555555555555ull;
+    u64 lo = key & EVEN, hi = (key >> 1) & EVEN;
+    u64 isT = lo & ~hi, isC = hi & ~lo, isG = lo & hi, isA = ~(lo | hi) & EVEN;
+    u64 bad = (isA & f.deny[0]) | (isT & f.deny[1]) | (isC & f.deny[2]) | (isG & f.deny[3]);
+    return bad == 0;
+}
+
+// relaxed, agent-scope 8-byte accesses for words shared between workgroups inside one launch
+// (self-validating {flag, value} granules: the only inter-workgroup hand-off used here)
+__device__ __forceinline__ u64 ld_agent(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(u64 *p, u64 v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace dnagpu

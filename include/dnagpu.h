@@ -1,0 +1,196 @@
+/*
+ * dnagpu.h -- C-ABI of the MI355X (gfx950) k-mer back-end.
+ *
+ * This is the drop-in boundary for the k-mer generation / filtering / counting path of the
+ * PostgreSQL extension sid2364/dna-sequences-pg-extension.  The extension's fmgr glue (dna.c)
+ * stays as it is; where its functions loop over bases on the CPU they call these entry points
+ * instead (INTEGRATION.md shows the glue).  Plain C: pointers, sizes, status codes.  No
+ * exceptions and no longjmp ever cross this boundary; no PostgreSQL, torch or C++ types appear.
+ *
+ * Data formats are the reference's own:
+ *   packed dna   uint64 words, base i in word i/32 at bits (2i mod 64)..+1, LSB first,
+ *                A=00 T=01 C=10 G=11, tail bits zero        (dna.c:42-47, 114-128)
+ *   kmer key     uint64, base i of the k-mer at bits 2i..2i+1 (dna.c:61-65, 397-420); the k-mer
+ *                at position p is bits [2p, 2p+2k) of the packed stream
+ *   qkmer        NUL-terminated IUPAC text, <= 32 chars      (dna.c:81-84, 876-900)
+ *
+ * Threading / process model: one context per process and device, created lazily AFTER fork (a
+ * PostgreSQL backend must not inherit a HIP runtime from the postmaster); calls on one context
+ * are synchronous with respect to the caller unless documented otherwise and not re-entrant.
+ * Every pointer named dev_* is device memory on the context's GPU; every other pointer is host
+ * memory owned by the caller.  The library never keeps a caller pointer after the call returns,
+ * except dnagpu_dna_wrap (documented there).
+ */
+#ifndef DNAGPU_H
+#define DNAGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNAGPU_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------
+ * 1..3 are the reference's own ERROR conditions on this path; dnagpu_strerror() returns the
+ * reference's exact message text for them so the glue can ereport() it unchanged. */
+#define DNAGPU_OK                       0
+#define DNAGPU_ERR_INVALID_K            1   /* dna.c:772-773 "Invalid k value: must be between 1 and 32" */
+#define DNAGPU_ERR_QKMER_LEN_MISMATCH   2   /* dna.c:1106-1108 "Qkmer pattern and kmer lengths do not match" */
+#define DNAGPU_ERR_PREFIX_TOO_LONG      3   /* dna.c:854-856 "Prefix length cannot exceed kmer length" */
+#define DNAGPU_ERR_QKMER_INVALID        4   /* dna.c:876-900 pattern empty / > 32 / non-IUPAC character */
+#define DNAGPU_ERR_BAD_ARG              5   /* NULL pointer, range outside the sequence, bad filter kind */
+#define DNAGPU_ERR_TOO_LARGE            6   /* more than 2^32 - 1 k-mers in one call */
+#define DNAGPU_ERR_NO_DEVICE            7   /* no usable gfx950 device / HIP runtime unavailable */
+#define DNAGPU_ERR_OOM                  8   /* device or host allocation failed */
+#define DNAGPU_ERR_HIP                  9   /* a HIP call or kernel failed; see dnagpu_last_error() */
+#define DNAGPU_ERR_INTERNAL             10
+
+const char *dnagpu_strerror(int status);
+/* detail text of the most recent failing call on the calling thread (HIP error string, etc.) */
+const char *dnagpu_last_error(void);
+int dnagpu_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+typedef struct dnagpu_ctx dnagpu_ctx;
+
+/* Creates a context on HIP device `device` (0-based).  Lazy, post-fork.  Owns one HIP stream and
+ * a pool of device work buffers that are recycled between calls. */
+int dnagpu_init(int device, dnagpu_ctx **out_ctx);
+void dnagpu_destroy(dnagpu_ctx *ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int dnagpu_synchronize(dnagpu_ctx *ctx);
+/* The context's hipStream_t (as void*), for callers that enqueue their own HIP work around it. */
+void *dnagpu_stream(dnagpu_ctx *ctx);
+/* Releases every pooled device buffer that is not in use. */
+int dnagpu_trim(dnagpu_ctx *ctx);
+/* Bytes of device memory currently held by the context (in use + pooled). */
+uint64_t dnagpu_device_bytes(dnagpu_ctx *ctx);
+
+/* ---- device-resident dna (the detoasted Dna* of dna.c:768, moved to HBM once) --------------- */
+typedef struct dnagpu_dna dnagpu_dna;
+
+/* Copies ceil(n_bases/32) packed words host -> device.  Replaces nothing in the reference by
+ * itself: it is the hand-off of dna->bit_sequence / dna->length (dna.c:45-46). */
+int dnagpu_dna_upload(dnagpu_ctx *ctx, const uint64_t *words, uint64_t n_bases, dnagpu_dna **out);
+/* Wraps n_words packed words already in device memory (no copy; the caller keeps them alive and
+ * unchanged until dnagpu_dna_free).  n_words >= ceil(n_bases/32). */
+int dnagpu_dna_wrap(dnagpu_ctx *ctx, const uint64_t *dev_words, uint64_t n_words, uint64_t n_bases,
+                    dnagpu_dna **out);
+/* Synthetic sequence generated on the device: word w = splitmix64(seed + w) (i.i.d. uniform bases,
+ * the distribution of data/create_dna.py:27-33), tail bits zero.  motif_len > 0 gives the
+ * repeat-rich variant: the second half of the sequence tiles the first motif_len bases. */
+int dnagpu_dna_synth(dnagpu_ctx *ctx, uint64_t seed, uint64_t n_bases, uint64_t motif_len,
+                     dnagpu_dna **out);
+int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t *words);
+uint64_t dnagpu_dna_length(const dnagpu_dna *dna);
+const uint64_t *dnagpu_dna_device_words(const dnagpu_dna *dna);
+void dnagpu_dna_free(dnagpu_ctx *ctx, dnagpu_dna *dna);
+
+/* ---- generate_kmers(dna, k)  (dna.c:743-837, dna--1.0.sql:188-191) -------------------------- */
+
+/* Row count of generate_kmers: n_bases - k + 1 (dna.c:781), 0 when n_bases < k (the reference
+ * underflows there).  DNAGPU_ERR_INVALID_K unless 1 <= k <= 32 (dna.c:771-773). */
+int dnagpu_kmer_count(uint64_t n_bases, int k, uint64_t *n_kmers);
+
+/* Writes the keys of rows [first, first+count) of generate_kmers(dna, k), in position order,
+ * duplicates kept, to out_keys (host memory, or device memory when out_on_device != 0).
+ * Replaces the per-row body dna.c:803-825 (decode to text, kmer_make, encode). */
+int dnagpu_generate_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                          uint64_t first, uint64_t count, uint64_t *out_keys, int out_on_device);
+
+/* ---- generate_kmers fused with a WHERE operator --------------------------------------------- */
+#define DNAGPU_FILTER_EQUALS       1   /* kmer = q         kmer_eq,     dna.c:655-668, 686-696 */
+#define DNAGPU_FILTER_STARTS_WITH  2   /* kmer ^@ prefix   starts_with, dna.c:842-866           */
+#define DNAGPU_FILTER_CONTAINS     3   /* qkmer @> kmer    contains,    dna.c:1064-1135         */
+
+typedef struct dnagpu_filter {
+    int32_t  kind;          /* DNAGPU_FILTER_*                                                   */
+    int32_t  length;        /* EQUALS / STARTS_WITH: length (bases) of the right-hand kmer       */
+    uint64_t bits;          /* EQUALS / STARTS_WITH: its bit_sequence                            */
+    char     pattern[36];   /* CONTAINS: the qkmer text, NUL-terminated                          */
+    int32_t  reserved;
+} dnagpu_filter;
+
+/* Rows of generate_kmers(dna,k) restricted to [first, first+count) that satisfy `filter`, in
+ * position order (the reference's row order, test.sql:86-92).  Keys go to out_keys and their
+ * positions to out_pos (either may be NULL), at most `cap` of each; *n_out receives the total
+ * number of matching rows even when it exceeds cap.  Errors exactly where the reference's operator
+ * raises them on the first row: CONTAINS with strlen(pattern) != k -> QKMER_LEN_MISMATCH,
+ * STARTS_WITH with length > k -> PREFIX_TOO_LONG (only when there is at least one row).  An EQUALS
+ * filter of another length matches nothing.  A 32-base prefix compares all 64 bits (the
+ * reference's shift-by-64 at dna.c:862 is undefined behaviour). */
+int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                                   const dnagpu_filter *filter, uint64_t first, uint64_t count,
+                                   uint64_t *out_keys, uint64_t *out_pos, uint64_t cap,
+                                   uint64_t *n_out, int out_on_device);
+
+/* ---- GROUP BY kmer, count(*)  (kmer_hash dna.c:722-735 + kmer_eq dna.c:686-696 drive
+ * PostgreSQL's HashAggregate in the reference; test.sql:95-119) ------------------------------ */
+typedef struct dnagpu_hist dnagpu_hist;
+
+/* Groups rows [first, first+count) of generate_kmers(dna,k) by key.  The result lives in device
+ * memory: n_distinct (key, count) pairs, keys ascending as uint64 (PostgreSQL leaves group order
+ * unspecified; ascending is this library's canonical order).  At most 2^32-1 rows per call. */
+int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                       uint64_t first, uint64_t count, dnagpu_hist **out);
+/* Same over an arbitrary array of n keys of k bases already in device memory.  dev_keys is used as
+ * scratch and its contents are unspecified afterwards. */
+int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out);
+
+uint64_t dnagpu_hist_distinct(const dnagpu_hist *h);   /* count(*) over groups                   */
+uint64_t dnagpu_hist_total(const dnagpu_hist *h);      /* sum(count)                              */
+const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h);
+const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
+/* Copies groups [first, first+count) to host arrays (either may be NULL). */
+int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
+                         uint64_t *keys, uint64_t *counts);
+/* total = sum(count), unique = count(*) FILTER (WHERE count = 1) (test.sql:112-114), checksum =
+ * wrapping sum over groups of an order-independent digest of (key, count), computed on device. */
+int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t *total, uint64_t *unique,
+                        uint64_t *checksum);
+void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h);
+
+/* ---- multi-GPU sharding of the count (one process per GPU; the exchange itself is the
+ * caller's collective, e.g. RCCL all-to-all) -------------------------------------------------
+ * Step 1 on every rank: the keys of rows [first, first+count) partitioned by owner.  Owner o of
+ * n_owners owns the keys whose top `owner_bits` bits d satisfy (d * n_owners) >> owner_bits == o
+ * (contiguous, ascending key ranges).  *dev_keys receives a device buffer of `count` keys grouped
+ * by owner, owner_offsets[0..n_owners] the group boundaries.  Free with dnagpu_buffer_free.
+ * Step 2 (caller): exchange the groups.  Step 3: dnagpu_count_keys on what was received; the
+ * concatenation of the owners' results in owner order is the global result, keys ascending. */
+int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                           uint64_t first, uint64_t count, int n_owners,
+                           uint64_t **dev_keys, uint64_t *owner_offsets);
+int dnagpu_buffer_alloc(dnagpu_ctx *ctx, uint64_t bytes, void **dev_ptr);
+void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr);
+
+/* ---- batched operators over arrays of keys (bulk scans of stored kmer columns) -------------- */
+
+/* kmer_hash (dna.c:722-735): PostgreSQL hash_any over the 8 bytes of bit_sequence. n keys in,
+ * n uint32 out; both host, or both device when on_device != 0. */
+int dnagpu_kmer_hash(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, uint32_t *out, int on_device);
+/* flags[i] = 1 when keys[i] (a kmer of k bases) satisfies `filter`, else 0.  Same error rules as
+ * dnagpu_generate_kmers_filtered. */
+int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
+                      const dnagpu_filter *filter, uint8_t *flags, int on_device);
+
+/* ---- instrumentation ------------------------------------------------------------------------
+ * Device time in milliseconds (HIP events on the context's stream) of the phases of the most
+ * recent dnagpu_count_kmers / dnagpu_count_keys call.  names[i] are static strings. */
+#define DNAGPU_MAX_PHASES 16
+typedef struct dnagpu_phase_times {
+    int         n;
+    const char *names[DNAGPU_MAX_PHASES];
+    float       ms[DNAGPU_MAX_PHASES];
+} dnagpu_phase_times;
+int dnagpu_last_phase_times(dnagpu_ctx *ctx, dnagpu_phase_times *out);
+/* Enables (1) / disables (0) per-phase event timing; off by default (it adds event records only). */
+int dnagpu_set_profiling(dnagpu_ctx *ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNAGPU_H */

@@ -1,0 +1,476 @@
+"""GPU parity: the HIP back-end (through the C-ABI, libdnagpu.so) against the CPU oracle on the same
+seeded inputs, against the reference's golden vectors, and -- at BASELINE.json sizes -- through
+size-independent properties.  Bit-exact: everything on this path is integer work."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def assert_same(got, want, what):
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, f"{what}: {got.shape[0]} values, oracle has {want.shape[0]}"
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        i = int(bad[0])
+        raise AssertionError(f"{what}: {bad.size} of {got.size} differ; first at {i}: "
+                             f"got {int(got[i]):#x}, oracle {int(want[i]):#x}")
+
+
+def check_hist(hist, ok, oc, what):
+    gk, gc = hist.download()
+    assert hist.distinct == len(ok), f"{what}: {hist.distinct} groups, oracle {len(ok)}"
+    assert_same(gk, ok, what + " keys")
+    assert_same(gc, oc, what + " counts")
+    assert hist.summary() == orc.hist_summary(ok, oc), what + " summary"
+
+
+# ------------------------------------------------------------------ input generator
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 64, 1000, 100_003])
+def test_synth_matches_oracle(ctx, n):
+    d = ctx.synth(0xABC, n)
+    assert_same(d.download(), orc.synth_words(0xABC, n), f"synth n={n}")
+    d.free()
+    d = ctx.synth(0xABC, n, motif_len=37)
+    assert_same(d.download(), orc.synth_words_repeat(0xABC, n, 37), f"synth repeat n={n}")
+    d.free()
+
+
+# ------------------------------------------------------------------ generate_kmers
+
+def test_generate_kmers_reference_rows(ctx, ref_vectors):
+    for v in ref_vectors["generate_kmers"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        rows = [orc.kmer_decode(b, v["k"]) for b in ctx.generate_kmers(d, v["k"])]
+        assert rows == v["rows"]
+        d.free()
+
+
+def test_generate_kmers_survey_bits(ctx, survey_vectors):
+    for v in survey_vectors["kmer_bits"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        assert [int(b) for b in ctx.generate_kmers(d, v["k"])] == [int(x, 16) for x in v["keys"]]
+        d.free()
+    for v in survey_vectors["kmer_bits_at"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        keys = ctx.generate_kmers(d, v["k"])
+        assert len(keys) == v["n"]
+        for p, x in v["at"].items():
+            assert int(keys[int(p)]) == int(x, 16)
+        d.free()
+
+
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 64, 65, 4095, 4096, 4097, 70_001])
+def test_generate_kmers_random(ctx, n):
+    words = orc.synth_words(1000 + n, n)
+    d = ctx.upload(words, n)
+    for k in (1, 2, 5, 15, 16, 17, 21, 31, 32):
+        want = orc.generate_kmers(words, n, k, faithful=False)
+        assert_same(ctx.generate_kmers(d, k), want, f"generate_kmers n={n} k={k}")
+    d.free()
+
+
+def test_generate_kmers_faithful_oracle_and_windows(ctx):
+    n = 20_011
+    words = orc.synth_words(77, n)
+    d = ctx.upload(words, n)
+    for k in (5, 21, 31, 32):
+        want = orc.generate_kmers(words, n, k, faithful=True)     # the reference's per-base loops
+        assert_same(ctx.generate_kmers(d, k), want, f"faithful k={k}")
+        for first, count in ((0, 1), (1, 4097), (31, 33), (len(want) - 1, 1), (len(want), 0), (4999, 10_001)):
+            assert_same(ctx.generate_kmers(d, k, first, count), want[first:first + count],
+                        f"window k={k} first={first} count={count}")
+    d.free()
+
+
+def test_generate_kmers_edge_cases(ctx, pkg):
+    words, n = orc.dna_encode("ACGTACG")
+    d = ctx.upload(words, n)
+    assert len(ctx.generate_kmers(d, 7)) == 1          # len == k
+    assert len(ctx.generate_kmers(d, 8)) == 0          # len == k-1
+    assert len(ctx.generate_kmers(d, 20)) == 0         # the reference underflows here; 0 rows
+    for k in (0, 33, -1):
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            ctx.generate_kmers(d, k)
+        assert ei.value.message == "Invalid k value: must be between 1 and 32"
+    with pytest.raises(pkg.DnaGpuError):
+        ctx.generate_kmers(d, 3, first=4, count=5)     # outside the row range
+    d.free()
+
+
+# ------------------------------------------------------------------ fused WHERE operators
+
+def test_filters_reference_rows(ctx, pkg, ref_vectors):
+    for v in ref_vectors["equals_filter"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        ln, bits = orc.kmer_encode(v["kmer"])
+        keys, _, tot = ctx.generate_kmers_filtered(d, v["k"], pkg.Filter.equals(ln, bits))
+        assert [orc.kmer_decode(b, v["k"]) for b in keys] == v["rows"] and tot == len(v["rows"])
+        d.free()
+    for v in ref_vectors["starts_with_filter"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        ln, bits = orc.kmer_encode(v["prefix"])
+        keys, _, _ = ctx.generate_kmers_filtered(d, v["k"], pkg.Filter.starts_with(ln, bits))
+        assert [orc.kmer_decode(b, v["k"]) for b in keys] == v["rows"]
+        d.free()
+    for v in ref_vectors["contains_filter"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        keys, _, _ = ctx.generate_kmers_filtered(d, v["k"], pkg.Filter.contains(v["pattern"]))
+        assert [orc.kmer_decode(b, v["k"]) for b in keys] == v["rows"]
+        d.free()
+
+
+def test_filters_survey_positions(ctx, pkg, survey_vectors):
+    for v in survey_vectors["contains_mask"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        _, pos, _ = ctx.generate_kmers_filtered(d, v["k"], pkg.Filter.contains(v["pattern"]))
+        want = v["positions"] if "positions" in v else [i for i, m in enumerate(v["match"]) if m]
+        assert [int(p) for p in pos] == want
+        d.free()
+
+
+PATTERNS_21 = ["NNNNNNNNNNWSNNNNNNNNN", "RYNNNNNNNNNNNNNNNNNNN", "ATCGUWSMKRYBDHVNNNNNN"[:21],
+               "BDHVBDHVBDHVBDHVBDHVB", "NNNNNNNNNNNNNNNNNNNNN", "ANNNNNNNNNNNNNNNNNNNT"]
+
+
+@pytest.mark.parametrize("n", [21, 4096 + 20, 250_007])
+def test_contains_random(ctx, pkg, n):
+    words = orc.synth_words(4242, n)
+    d = ctx.upload(words, n)
+    for pat in PATTERNS_21:
+        wk, wp = orc.generate_kmers_contains(words, n, 21, pat)
+        gk, gp, tot = ctx.generate_kmers_filtered(d, 21, pkg.Filter.contains(pat))
+        assert tot == len(wk), f"{pat}: {tot} matches, oracle {len(wk)}"
+        assert_same(gk, wk, f"contains {pat} keys")
+        assert_same(gp, wp, f"contains {pat} positions")
+    # every IUPAC letter at k=1 and a 32-long pattern
+    for ch in "ATCGUWSMKRYBDHVN":
+        wk, wp = orc.generate_kmers_contains(words, n, 1, ch)
+        gk, gp, _ = ctx.generate_kmers_filtered(d, 1, pkg.Filter.contains(ch))
+        assert_same(gp, wp, f"contains '{ch}' positions")
+    if n >= 32:
+        pat = "NWSNNNNNNNNNNNNNNNNNNNNNNNNNNNRY"
+        assert len(pat) == 32
+        wk, wp = orc.generate_kmers_contains(words, n, 32, pat)
+        gk, gp, _ = ctx.generate_kmers_filtered(d, 32, pkg.Filter.contains(pat))
+        assert_same(gk, wk, "contains k=32 keys")
+        assert_same(gp, wp, "contains k=32 positions")
+    d.free()
+
+
+def test_starts_with_and_equals_random(ctx, pkg):
+    n = 300_001
+    words = orc.synth_words(99, n)
+    d = ctx.upload(words, n)
+    for k, prefix in ((3, "AC"), (21, "ACG"), (21, "G"), (31, "TTTT"), (32, "CA"), (5, "ACGTA")):
+        ln, bits = orc.kmer_encode(prefix)
+        wk, wp = orc.generate_kmers_starts_with(words, n, k, ln, bits)
+        gk, gp, tot = ctx.generate_kmers_filtered(d, k, pkg.Filter.starts_with(ln, bits))
+        assert tot == len(wk)
+        assert_same(gk, wk, f"^@ {prefix} k={k} keys")
+        assert_same(gp, wp, f"^@ {prefix} k={k} positions")
+    # equality: pick a k-mer that occurs, at k=8 it repeats
+    keys8 = orc.generate_kmers(words, n, 8, faithful=False)
+    q = int(keys8[1234])
+    wk, wp = orc.generate_kmers_equals(words, n, 8, 8, q)
+    gk, gp, tot = ctx.generate_kmers_filtered(d, 8, pkg.Filter.equals(8, q))
+    assert tot == len(wk) and tot >= 1
+    assert_same(gp, wp, "= positions")
+    # a kmer of another length never equals (kmer_eq compares lengths, dna.c:658)
+    _, _, tot = ctx.generate_kmers_filtered(d, 8, pkg.Filter.equals(7, q & 0x3FFF))
+    assert tot == 0
+    # window + cap smaller than the number of matches: first `cap` rows, total still reported
+    ln, bits = orc.kmer_encode("A")
+    wk, wp = orc.generate_kmers_starts_with(words, n, 21, ln, bits)
+    gk, gp, tot = ctx.generate_kmers_filtered(d, 21, pkg.Filter.starts_with(ln, bits), cap=1000)
+    assert tot == len(wk) and len(gk) == 1000
+    assert_same(gk, wk[:1000], "cap keys")
+    sel = (wp >= 5000) & (wp < 5000 + 123_456)
+    gk, gp, tot = ctx.generate_kmers_filtered(d, 21, pkg.Filter.starts_with(ln, bits), first=5000, count=123_456)
+    assert_same(gp, wp[sel], "window positions")
+    d.free()
+
+
+def test_filter_errors(ctx, pkg):
+    words, n = orc.dna_encode("ACGTACGTAC")
+    d = ctx.upload(words, n)
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.generate_kmers_filtered(d, 4, pkg.Filter.contains("ACG"))
+    assert ei.value.message == "Qkmer pattern and kmer lengths do not match"
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.generate_kmers_filtered(d, 3, pkg.Filter.starts_with(4, 0))
+    assert ei.value.message == "Prefix length cannot exceed kmer length"
+    with pytest.raises(pkg.DnaGpuError):
+        ctx.generate_kmers_filtered(d, 3, pkg.Filter.contains("AZG"))
+    with pytest.raises(pkg.DnaGpuError):
+        ctx.generate_kmers_filtered(d, 3, pkg.Filter.contains(""))
+    # no rows -> the operator is never evaluated -> no error (as in the reference)
+    _, _, tot = ctx.generate_kmers_filtered(d, 11, pkg.Filter.contains("ACG"))
+    assert tot == 0
+    # 32-base prefix: compares all 64 bits (the reference's shift by 64 is undefined behaviour)
+    w32, n32 = orc.dna_encode("ACGT" * 8 + "A")
+    d32 = ctx.upload(w32, n32)
+    ln, bits = orc.kmer_encode("ACGT" * 8)
+    _, pos, tot = ctx.generate_kmers_filtered(d32, 32, pkg.Filter.starts_with(ln, bits))
+    assert tot == 1 and int(pos[0]) == 0
+    d.free()
+    d32.free()
+
+
+# ------------------------------------------------------------------ GROUP BY count(*)
+
+def test_count_reference_groups(ctx, ref_vectors, survey_vectors):
+    for v in ref_vectors["count"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        h = ctx.count_kmers(d, v["k"])
+        gk, gc = h.download()
+        assert {orc.kmer_decode(a, v["k"]): int(c) for a, c in zip(gk, gc)} == v["groups"]
+        h.free()
+        d.free()
+    for v in ref_vectors["summary"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        h = ctx.count_kmers(d, v["k"])
+        total, distinct, unique, _ = h.summary()
+        assert (total, distinct, unique) == (v["total"], v["distinct"], v["unique"])
+        h.free()
+        d.free()
+    for v in survey_vectors["histogram_bits"]:
+        words, n = orc.dna_encode(v["dna"])
+        d = ctx.upload(words, n)
+        h = ctx.count_kmers(d, v["k"])
+        gk, gc = h.download()
+        assert {int(a): int(c) for a, c in zip(gk, gc)} == {int(a, 16): c for a, c in v["groups"].items()}
+        h.free()
+        d.free()
+
+
+COUNT_SIZES = [1, 2, 100, 4095, 4096, 4097, 8193, 50_000, 1_000_003]
+
+
+@pytest.mark.parametrize("n", COUNT_SIZES)
+def test_count_random(ctx, n):
+    words = orc.synth_words(31337 + n, n)
+    d = ctx.upload(words, n)
+    for k in (1, 2, 3, 5, 6, 8, 11, 13, 16, 21, 31, 32):
+        if n < k:
+            h = ctx.count_kmers(d, k)
+            assert h.distinct == 0 and h.total == 0
+            h.free()
+            continue
+        ok, oc = orc.count_kmers(words, n, k)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"count n={n} k={k}")
+        h.free()
+    d.free()
+
+
+def test_count_faithful_oracle(ctx):
+    # the oracle's faithful path (per-base decode + re-encode + hash aggregate), config-1 shaped
+    n = 200_000
+    words = orc.synth_words(5, n)
+    d = ctx.upload(words, n)
+    for k in (5, 21, 31):
+        ok, oc = orc.count_kmers(words, n, k, faithful=True)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"faithful count k={k}")
+        h.free()
+    d.free()
+
+
+@pytest.mark.parametrize("n,motif", [(100_000, 1000), (3_000_000, 1000), (2_000_000, 7), (500_000, 250_000)])
+def test_count_repeat_rich(ctx, n, motif):
+    words = orc.synth_words_repeat(4, n, motif)
+    d = ctx.synth(4, n, motif_len=motif)
+    assert_same(d.download(), words, "repeat input")
+    for k in (5, 12, 21, 31, 32):
+        ok, oc = orc.count_kmers(words, n, k)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"repeat-rich n={n} motif={motif} k={k}")
+        h.free()
+    d.free()
+
+
+@pytest.mark.parametrize("seq", ["A" * 100_000, "G" * 70_001, "AT" * 60_000, "ACGT" * 50_000,
+                                 "A" * 5000 + "C" * 5000 + "G" * 5000 + "T" * 5000])
+def test_count_low_complexity(ctx, seq):
+    words, n = orc.dna_encode(seq)
+    d = ctx.upload(words, n)
+    for k in (1, 4, 16, 31, 32):
+        ok, oc = orc.count_kmers(words, n, k)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"low complexity {seq[:8]}..x{n} k={k}")
+        h.free()
+    d.free()
+
+
+def test_count_windows_and_linearity(ctx):
+    n, k = 700_000, 21
+    words = orc.synth_words_repeat(8, n, 5000)
+    d = ctx.upload(words, n)
+    keys = orc.generate_kmers(words, n, k, faithful=False)
+    for first, count in ((0, 1), (17, 4096), (1000, 300_000), (len(keys) - 5, 5), (123, 0)):
+        ok, oc = orc.count_keys(keys[first:first + count])
+        h = ctx.count_kmers(d, k, first, count)
+        check_hist(h, ok, oc, f"count window first={first} count={count}")
+        h.free()
+    # linearity: the histogram of the whole equals the merge of the histograms of two halves
+    half = len(keys) // 2
+    ha = ctx.count_kmers(d, k, 0, half)
+    hb = ctx.count_kmers(d, k, half, len(keys) - half)
+    hw = ctx.count_kmers(d, k)
+    ak, ac = ha.download()
+    bk, bc = hb.download()
+    merged = {}
+    for kk, cc in zip(np.concatenate([ak, bk]), np.concatenate([ac, bc])):
+        merged[int(kk)] = merged.get(int(kk), 0) + int(cc)
+    wk, wc = hw.download()
+    assert merged == {int(a): int(b) for a, b in zip(wk, wc)}
+    for h in (ha, hb, hw):
+        h.free()
+    d.free()
+
+
+def test_count_keys_device(ctx):
+    # dnagpu_count_keys over an arbitrary key array produced on the device
+    n, k = 600_000, 31
+    d = ctx.synth(21, n)
+    words = d.download()
+    nk = n - k + 1
+    buf = ctx.buffer_alloc(nk * 8)
+    ctx.generate_kmers_device(d, k, 0, nk, buf)
+    h = ctx.count_keys_device(buf, nk, k)
+    ok, oc = orc.count_kmers(words, n, k)
+    check_hist(h, ok, oc, "count_keys")
+    h.free()
+    ctx.buffer_free(buf)
+    d.free()
+
+
+# ------------------------------------------------------------------ batched operators
+
+def test_kmer_hash_batch(ctx, survey_vectors):
+    for v in survey_vectors["kmer_hash"]:
+        _, bits = orc.kmer_encode(v["kmer"])
+        got = int(ctx.kmer_hash(np.array([bits], dtype=np.uint64))[0])
+        assert got == v["hash"] & 0xFFFFFFFF
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 1 << 63, size=100_000, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    want = np.array([orc.lib().orc_kmer_hash(int(x)) for x in keys[:5000]], dtype=np.uint32)
+    got = ctx.kmer_hash(keys)
+    assert_same(got[:5000], want, "kmer_hash")
+
+
+def test_kmer_match_batch(ctx, pkg):
+    n, k = 50_000, 21
+    words = orc.synth_words(6, n)
+    keys = orc.generate_kmers(words, n, k, faithful=False)
+    for pat in PATTERNS_21[:3]:
+        _, wp = orc.generate_kmers_contains(words, n, k, pat)
+        want = np.zeros(len(keys), dtype=bool)
+        want[wp.astype(np.int64)] = True
+        assert np.array_equal(ctx.kmer_match(keys, k, pkg.Filter.contains(pat)), want)
+    ln, bits = orc.kmer_encode("ACG")
+    _, wp = orc.generate_kmers_starts_with(words, n, k, ln, bits)
+    want = np.zeros(len(keys), dtype=bool)
+    want[wp.astype(np.int64)] = True
+    assert np.array_equal(ctx.kmer_match(keys, k, pkg.Filter.starts_with(ln, bits)), want)
+    with pytest.raises(pkg.DnaGpuError):
+        ctx.kmer_match(keys, k, pkg.Filter.contains("ACG"))
+
+
+# ------------------------------------------------------------------ multi-GPU step 1 (owner partition)
+
+@pytest.mark.parametrize("n_owners", [1, 2, 3, 8])
+def test_partition_by_owner(ctx, n_owners):
+    import ctypes as C
+    n, k = 400_000, 31
+    d = ctx.synth(0xD2A0003, n)
+    words = d.download()
+    keys = orc.generate_kmers(words, n, k, faithful=False)
+    for first, count in ((0, len(keys)), (1000, 250_000)):
+        ptr, offs = ctx.partition_kmers(d, k, first, count, n_owners)
+        assert int(offs[0]) == 0 and int(offs[-1]) == count and np.all(np.diff(offs.astype(np.int64)) >= 0)
+        # read the device buffer back through a hist-free path: count each owner's slice separately
+        bits = 10
+        sub = keys[first:first + count]
+        owner = ((sub >> np.uint64(2 * k - bits)).astype(np.uint64) * np.uint64(n_owners)) >> np.uint64(bits)
+        for o in range(n_owners):
+            lo, hi = int(offs[o]), int(offs[o + 1])
+            want = np.sort(sub[owner == o])
+            assert hi - lo == len(want), f"owner {o}: {hi - lo} keys, oracle {len(want)}"
+            if hi > lo:
+                h = ctx.count_keys_device(C.c_void_p(ptr + lo * 8), hi - lo, k)
+                ok, oc = orc.count_keys(want)
+                check_hist(h, ok, oc, f"owner {o}/{n_owners} slice")
+                h.free()
+        ctx.buffer_free(ptr)
+    d.free()
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes (properties)
+
+def test_config2_k21_100M_against_oracle_summary(ctx):
+    """configs[1]: k=21 over 100 Mbase synthetic, seed 0xD2A0001: full histogram digest vs oracle."""
+    n, k, seed = 100_000_000, 21, 0xD2A0001
+    d = ctx.synth(seed, n)
+    h = ctx.count_kmers(d, k)
+    total, distinct, unique, checksum = h.summary()
+    assert total == n - k + 1
+    words = orc.synth_words(seed, n)
+    ok, oc = orc.count_kmers(words, n, k)
+    assert (total, distinct, unique, checksum) == orc.hist_summary(ok, oc)
+    gk, gc = h.download()
+    assert_same(gk, ok, "config 2 keys")
+    assert_same(gc, oc, "config 2 counts")
+    h.free()
+    d.free()
+
+
+def test_config3_k31_chr1_scale_properties(ctx):
+    """configs[2]: k=31 over 248,956,422 bases: sortedness, totals, and window additivity."""
+    n, k, seed = 248_956_422, 31, 0xD2A0002
+    d = ctx.synth(seed, n)
+    h = ctx.count_kmers(d, k)
+    total, distinct, unique, checksum = h.summary()
+    assert total == n - k + 1
+    gk, gc = h.download()
+    assert np.all(gk[1:] > gk[:-1]), "keys not strictly ascending"
+    assert int(gc.sum()) == total and int((gc == 1).sum()) == unique
+    # uniform 62-bit keys: almost all distinct
+    assert distinct > total - 100
+    # spot check: 200 random positions' k-mers are present with count >= 1
+    rng = np.random.default_rng(1)
+    pos = rng.integers(0, n - k + 1, size=200)
+    words = d.download()
+    for p in pos:
+        key = orc.generate_kmers(words, n, k, first=int(p), count=1, faithful=False)[0]
+        i = int(np.searchsorted(gk, key))
+        assert i < len(gk) and gk[i] == key
+    h.free()
+    d.free()
