@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/sec for the k=31 count over 3 Gbase synthetic (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full GROUP BY count over the whole synthetic sequence (extraction fused in), input
+already resident in HBM.  N=1: the single-GPU path (dnagpu_count_kmers) on all 3 Gbase.  N>1:
+the same 3 Gbase sharded by contiguous chunk over the ranks (strong scaling), one RCCL all-to-all
+of the keys by owner, local count (sharded.py).  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel of the step: algorithmic bytes / its device time (HIP events on
+                the library's stream) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (faithful restatement of the reference's per-base loops + hash
+                aggregate) timed on this box's host cores on a bounded sample of the same stream
+  job_roofline  SURVEY.md 8(d)'s two whole-job fractions (read_fraction, alg_fraction)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SEED = 0xD2A0003
+CPU_SAMPLE_BASES = 24_000_000  # bounded sample for the CPU baseline (about 10-20 s on one core)
+
+# algorithmic HBM bytes of each phase per k-mer (n) / per distinct k-mer (d); DESIGN.md "kernels"
+PHASE_BYTES = {
+    "hist0": lambda n, d: 0.25 * n,                 # packed input only
+    "scatter0": lambda n, d: 0.25 * n + 8.0 * n,    # packed input in, keys out
+    "hist": lambda n, d: 8.0 * n,                   # keys in
+    "scatter": lambda n, d: 16.0 * n,               # keys in, keys out
+    "leaves": lambda n, d: 8.0 * n + 16.0 * d,      # keys in, (key, count) groups out
+}
+
+
+def phase_kind(name):
+    if name == "leaves":
+        return "leaves"
+    if name.endswith("_hist"):
+        return "hist0" if name.startswith("level0") else "hist"
+    if name.endswith("_scatter"):
+        return "scatter0" if name.startswith("level0") else "scatter"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-bases", type=float, default=3e9)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_bases, k = int(args.n_bases), args.k
+    n_kmers = n_bases - k + 1
+
+    import torch
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    ctx = pkg.Context(local_rank)
+    ctx.set_profiling(True)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    phases_acc = {}
+    distinct = [0]
+
+    if world == 1:
+        dna = ctx.synth(SEED, n_bases)
+
+        def step():
+            h = ctx.count_kmers(dna, k)
+            distinct[0] = h.distinct
+            for name, ms in ctx.last_phase_times():
+                phases_acc.setdefault(name, []).append(ms)
+            h.free()
+    else:
+        import importlib
+        sh = importlib.import_module(pkg.__name__ + ".sharded")
+        engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", local_rank))
+        state = {"dna": None}
+
+        def step():
+            h, state["dna"] = sh.count_sharded(engine, SEED, n_bases, k, rank, world, state["dna"])
+            distinct[0] = h.distinct
+            for name, ms in ctx.last_phase_times():
+                phases_acc.setdefault(name, []).append(ms)
+            h.free()
+
+    for _ in range(args.warmup):
+        step()
+    phases_acc.clear()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dsum = torch.tensor([distinct[0]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(dsum)
+        distinct[0] = int(dsum.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_kmers * args.steps / elapsed
+        # dominant kernel of a step on this rank, by mean device time
+        means = {name: sum(v) / len(v) for name, v in phases_acc.items()}
+        kern = {n_: m for n_, m in means.items() if phase_kind(n_)}
+        dom = max(kern, key=kern.get) if kern else None
+        roofline = None
+        if dom:
+            per_rank_n = n_kmers / world
+            per_rank_d = distinct[0] / world
+            alg_bytes = PHASE_BYTES[phase_kind(dom)](per_rank_n, per_rank_d)
+            achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 3),
+                        "traffic": load_traffic(dom)}
+        b_in = 8 * ((n_bases + 31) // 32)
+        t_step = elapsed / args.steps
+        job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS / world, 5),
+               "alg_fraction": round((b_in + 16 * distinct[0]) / t_step / 1e9 / HBM_PEAK_GBS / world, 4),
+               "alg_bytes_per_kmer": round((b_in + 16 * distinct[0]) / n_kmers, 3)}
+        line = {
+            "metric": "k-mers/sec for k=31 count over 3 Gbase synthetic; % of HBM-read roofline",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"k={k} count over {n_bases} synthetic bases (splitmix64 seed {SEED:#x}), "
+                                   f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-to-all by key owner'}",
+                       "n_bases": n_bases, "k": k, "distinct": distinct[0]},
+            "roofline": roofline,
+            "job_roofline": job,
+            "phases_ms": {n_: round(m, 3) for n_, m in means.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(k)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile, if one matches."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return t.get(kernel)
+    except Exception:
+        return None
+
+
+def cpu_baseline(k):
+    """The oracle timed on this box's host: one core, like the reference's one PostgreSQL backend
+    (generate_kmers is not PARALLEL SAFE, dna--1.0.sql:188-191).  The oracle is only the timed CPU
+    baseline here; nothing of the GPU result comes from it."""
+    import oracle as orc
+    n = CPU_SAMPLE_BASES
+    words = orc.synth_words(SEED, n)
+    t0 = time.perf_counter()
+    keys, counts = orc.count_kmers(words, n, k, faithful=True)
+    dt = time.perf_counter() - t0
+    return {"value": (n - k + 1) / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} bases of the same synthetic stream, k={k}: per-base decode + kmer_make "
+                      f"re-encode (dna.c:803-825) + hash aggregate on kmer_hash/kmer_eq, {dt:.1f} s",
+            "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

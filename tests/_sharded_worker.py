@@ -1,0 +1,101 @@
+"""Worker of the N>1 tests: one rank of a sharded count (sharded.py), gloo rendezvous on 127.0.0.1.
+engine=oracle : the CPU oracle stands in for the GPU (tests the host logic: shards, halo, owner split
+                sizes, the all-to-all) -- runs anywhere
+engine=gpu    : the product engine on cuda:0 (every rank shares the one GPU of the box; the
+                exchange is staged through the host because gloo has no device all-to-all)
+Rank 0 writes {"ok": bool, ...} as JSON to the path in argv."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle as orc  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+
+class OracleHist:
+    def __init__(self, keys, counts):
+        self.keys, self.counts = keys, counts
+        self.distinct, self.total = len(keys), int(counts.sum()) if len(counts) else 0
+
+    def download(self):
+        return self.keys, self.counts
+
+    def free(self):
+        pass
+
+
+class OracleEngine:
+    """Same interface as sharded.GpuEngine, computed by the oracle (tests only)."""
+
+    def make_shard(self, seed, base_lo, base_hi):
+        n = base_hi - base_lo
+        return (orc.synth_words(seed + base_lo // 32, n), n)
+
+    def partition(self, dna, k, count, world):
+        words, n = dna
+        keys = orc.generate_kmers(words, n, k, 0, count, faithful=False)
+        bits = min(2 * k, 10)
+        owner = ((keys >> np.uint64(2 * k - bits)) * np.uint64(world)) >> np.uint64(bits)
+        order = np.argsort(owner, kind="stable")
+        offs = [int(x) for x in np.searchsorted(owner[order], np.arange(world + 1))]
+        return torch.from_numpy(keys[order].view(np.int64).copy()), offs
+
+    def release(self):
+        pass
+
+    def empty(self, n):
+        return torch.empty(n, dtype=torch.int64)
+
+    def count_keys(self, keys_t, k):
+        k_, c_ = orc.count_keys(keys_t.numpy().view(np.uint64))
+        return OracleHist(k_, c_)
+
+    def free_dna(self, dna):
+        pass
+
+
+def main():
+    engine_name, n_bases, k, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package()
+    sh = importlib.import_module(pkg.__name__ + ".sharded")
+    seed = 0xD2A0003
+    ctx = None
+    if engine_name == "gpu":
+        ctx = pkg.Context(0)
+        engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", 0))
+    else:
+        engine = OracleEngine()
+    hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world)
+    keys, counts = hist.download()
+    parts = [None] * world
+    dist.all_gather_object(parts, (np.asarray(keys), np.asarray(counts)))
+    if rank == 0:
+        gk = np.concatenate([p[0] for p in parts])
+        gc = np.concatenate([p[1] for p in parts])
+        words = orc.synth_words(seed, n_bases)
+        ok, oc = orc.count_kmers(words, n_bases, k)
+        res = {"ok": bool(np.array_equal(gk, ok) and np.array_equal(gc, oc)),
+               "distinct": int(len(gk)), "oracle_distinct": int(len(ok)),
+               "sorted": bool(np.all(gk[1:] > gk[:-1])) if len(gk) > 1 else True,
+               "per_rank": [int(len(p[0])) for p in parts]}
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    hist.free()
+    engine.free_dna(dna)
+    dist.barrier()
+    dist.destroy_process_group()
+    if ctx is not None:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""N>1 path (sharded.py): world_size-2/3 gloo runs.  CPU: the oracle stands in for the GPU engine
+and checks the host logic; GPU: the product engine, all ranks on the box's one GPU."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from __graft_entry__ import ROOT, load_package
+
+
+def run_world(engine, world, n_bases, k, tmp_path, port):
+    out = tmp_path / f"res_{engine}_{world}_{n_bases}_{k}.json"
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"),
+                                       engine, str(n_bases), str(k), str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return json.loads(out.read_text())
+
+
+def test_shard_ranges_cover_exactly_once():
+    pkg = load_package()
+    sh = importlib.import_module(pkg.__name__ + ".sharded")
+    for n, k, w in [(1000, 31, 2), (1000, 31, 8), (64, 32, 3), (31, 31, 4), (30, 31, 2), (3_000_000_000, 31, 8)]:
+        r = sh.shard_ranges(n, k, w)
+        n_kmers = max(n - k + 1, 0)
+        assert sum(x[1] for x in r) == n_kmers
+        pos = 0
+        for first, cnt, lo, hi in r:
+            assert first == pos and lo % 32 == 0
+            if cnt:
+                assert hi == min(first + cnt + k - 1, n)      # k-1 base halo, clipped at the end
+            pos += cnt
+
+
+@pytest.mark.parametrize("world,n_bases,k", [(2, 200_000, 31), (3, 100_001, 21), (2, 5000, 8)])
+def test_sharded_count_gloo_oracle_engine(tmp_path, world, n_bases, k):
+    res = run_world("oracle", world, n_bases, k, tmp_path, 29511 + world)
+    assert res["ok"] and res["sorted"], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 21)])
+def test_sharded_count_gloo_gpu_engine(tmp_path, world, n_bases, k):
+    res = run_world("gpu", world, n_bases, k, tmp_path, 29521 + world)
+    assert res["ok"] and res["sorted"], res
