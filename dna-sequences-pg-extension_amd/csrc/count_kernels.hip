@@ -18,16 +18,14 @@
 //   which is how heavy hitters and small k terminate.
 //
 // Output: groups in ascending key order; bit-exact against the oracle's sorted hash-aggregate.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace dnagpu {
 
-constexpr int SC_THREADS = 512;               // level_hist / level_scatter workgroup
-constexpr int SC_ITEMS = 16;
-constexpr int SC_TILE = SC_THREADS * SC_ITEMS;   // 8192 keys staged in LDS per tile
-constexpr int LF_THREADS = 512;               // leaf workgroup
-constexpr int LF_ITEMS = LEAF_CAP / LF_THREADS;  // 8
-constexpr int LF_SUB_BITS = 12;               // counting-sort bins per leaf: 4096
+constexpr int SC_THREADS = 1024;              // level_hist workgroup
+constexpr int SC_TILE = 8192;                 // keys staged in LDS per scatter tile
 
 int scatter_tile_keys() { return SC_TILE; }
 int scatter_threads() { return SC_THREADS; }
@@ -47,6 +45,7 @@ __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
     const int b = tid * per;
     const int e = (b + per < n) ? b + per : n;
     u32 sum = 0;
+#pragma unroll 1
     for (int i = b; i < e; i++)
         sum += arr[i];
     u32 inc = sum;
@@ -58,14 +57,15 @@ __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
     if (lane == 63)
         wtmp[wave] = inc;
     __syncthreads();
+    // wave-uniform trip count: keeps the prefix in scalar code instead of NT/64 hoisted predicates
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     u32 wbase = 0, total = 0;
-    for (int w = 0; w < NT / 64; w++) {
-        u32 t = wtmp[w];
-        if (w < wave)
-            wbase += t;
-        total += t;
-    }
+    for (int w = 0; w < wv; w++)
+        wbase += wtmp[w];
+    for (int w = 0; w < NT / 64; w++)
+        total += wtmp[w];
     u32 run = wbase + inc - sum;
+#pragma unroll 1
     for (int i = b; i < e; i++) {
         u32 v = arr[i];
         arr[i] = run;
@@ -381,20 +381,20 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
 //   stage  keys written digit-sorted into LDS
 //   write  thread i copies staged key i to out[base[d] + (i - excl[d])]: each digit's run is one
 //          contiguous, coalesced segment
-template <bool SRC_DNA>
-__global__ __launch_bounds__(SC_THREADS, 4) void level_scatter_kernel(const Node *__restrict__ nodes,
+template <bool SRC_DNA, int NT, int ITEMS, int MINW>
+__global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__restrict__ nodes,
                                                                    const Chunk *__restrict__ chunks, u32 n_chunks,
                                                                    const u64 *__restrict__ words, u64 n_words,
                                                                    u64 first, u64 mask, u64 *__restrict__ buf0,
                                                                    u64 *__restrict__ buf1,
                                                                    const u32 *__restrict__ hist,
-                                                                   const u32 *__restrict__ tot)
+                                                                   const u32 *__restrict__ tot, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *stage = reinterpret_cast<u64 *>(smem);                         // SC_TILE keys
-    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)SC_TILE * 8);    // ROW_STRIDE + 1
+    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)(NT * ITEMS) * 8);    // ROW_STRIDE + 1
     u32 *offs = excl + ROW_STRIDE + 4;                                  // ROW_STRIDE
-    u32 *wtmp = offs + ROW_STRIDE;                                      // SC_THREADS / 64
+    u32 *wtmp = offs + ROW_STRIDE;                                      // NT / 64
 
     if (blockIdx.x >= n_chunks)
         return;
@@ -413,62 +413,84 @@ __global__ __launch_bounds__(SC_THREADS, 4) void level_scatter_kernel(const Node
 
     const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
     const u32 *trow = tot + (u64)nd.chunk_base * ROW_STRIDE;
-    for (u32 d = threadIdx.x; d < R; d += SC_THREADS)
+#pragma unroll 1
+    for (u32 d = threadIdx.x; d < R; d += NT)
         offs[d] = hrow[d] + trow[d];
 
-    for (u32 t0 = 0; t0 < ch.len; t0 += SC_TILE) {
-        const u32 tn = ch.len - t0 < (u32)SC_TILE ? ch.len - t0 : (u32)SC_TILE;
-        for (u32 d = threadIdx.x; d <= R; d += SC_THREADS)
+    for (u32 t0 = 0; t0 < ch.len; t0 += NT * ITEMS) {
+        const u32 tn = ch.len - t0 < (u32)(NT * ITEMS) ? ch.len - t0 : (u32)(NT * ITEMS);
+#pragma unroll 1
+        for (u32 d = threadIdx.x; d <= R; d += NT)
             excl[d] = 0;
-        // keys of this thread: the dna root recomputes them from three packed words (cheaper than
-        // holding 16 keys in registers); key nodes load them once
-        Win16 w;
-        u64 key[SRC_DNA ? 1 : SC_ITEMS];
+        // Keys of this thread.  Slots past the end of the chunk are not branched around: they count
+        // in an extra digit R, which sorts them behind every real key (no exec-mask juggling).
+        u64 key[ITEMS];
         if (SRC_DNA) {
-            w = win16_load(words, n_words, first + origin + t0 + threadIdx.x * 16);
+            Win16 w = win16_load(words, n_words, first + origin + t0 + threadIdx.x * ITEMS);
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                key[j] = win16_key(w, j, mask);
         } else {
 #pragma unroll
-            for (int j = 0; j < SC_ITEMS; j++) {
-                u32 i = threadIdx.x + j * SC_THREADS;
-                key[SRC_DNA ? 0 : j] = i < tn ? src[t0 + i] : 0;
+            for (int j = 0; j < ITEMS; j++) {
+                u32 i = threadIdx.x + j * NT;
+                key[j] = src[t0 + (i < tn ? i : tn - 1)];
             }
         }
         __syncthreads();
-        u32 rank[SC_ITEMS];
+        u32 pos[ITEMS];        // rank inside the digit, then staged position
 #pragma unroll
-        for (int j = 0; j < SC_ITEMS; j++) {
-            u32 i = SRC_DNA ? threadIdx.x * 16 + j : threadIdx.x + j * SC_THREADS;
-            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
-            rank[j] = 0;
-            if (i < tn)
-                rank[j] = atomicAdd(&excl[(u32)(kv >> shift) & dmask], 1u);
+        for (int j = 0; j < ITEMS; j++) {
+            u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
+            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
+            pos[j] = atomicAdd(&excl[d], 1u);
         }
         __syncthreads();
-        block_scan_inplace<SC_THREADS>(excl, (int)R, wtmp);
-        if (threadIdx.x == 0)
-            excl[R] = tn;
+        block_scan_inplace<NT>(excl, (int)R + 1, wtmp);      // excl[R] = tn afterwards
 #pragma unroll
-        for (int j = 0; j < SC_ITEMS; j++) {
-            u32 i = SRC_DNA ? threadIdx.x * 16 + j : threadIdx.x + j * SC_THREADS;
-            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
-            if (i < tn)
-                stage[excl[(u32)(kv >> shift) & dmask] + rank[j]] = kv;
+        for (int j = 0; j < ITEMS; j++) {
+            u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
+            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
+            stage[excl[d] + pos[j]] = key[j];
         }
         __syncthreads();
-        for (u32 i = threadIdx.x; i < tn; i += SC_THREADS) {
+#pragma unroll 2
+        for (u32 i = threadIdx.x; i < tn; i += NT) {
             u64 kv = stage[i];
             u32 d = (u32)(kv >> shift) & dmask;
-            dst[(u64)offs[d] + (i - excl[d])] = kv;
+            if (dbg & 1)
+                dst[origin + t0 + i] = kv;      // timing ablation: same bytes, written linearly
+            else
+                dst[(u64)offs[d] + (i - excl[d])] = kv;
         }
         __syncthreads();
-        for (u32 d = threadIdx.x; d < R; d += SC_THREADS)
+#pragma unroll 1
+        for (u32 d = threadIdx.x; d < R; d += NT)
             offs[d] += excl[d + 1] - excl[d];
         __syncthreads();
     }
 }
 
-constexpr size_t SC_SMEM = (size_t)SC_TILE * 8 + (size_t)(ROW_STRIDE + 4) * 4 + (size_t)ROW_STRIDE * 4 +
-                           (SC_THREADS / 64) * 4;
+constexpr size_t SC_SMEM = (size_t)SC_TILE * 8 + (size_t)(ROW_STRIDE + 4) * 4 + (size_t)ROW_STRIDE * 4 + 16 * 4;
+
+template <int NT, int ITEMS, int MINW>
+static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, const Node *nodes, const Chunk *chunks,
+                                   const u64 *words, u64 n_words, u64 first, u64 mask, u64 *buf0, u64 *buf1,
+                                   const u32 *hist, const u32 *tot)
+{
+    static_assert(NT * ITEMS == SC_TILE, "tile size is fixed");
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results are invalid when set
+        dbg = e ? atoi(e) : 0;
+    }
+    if (src_dna)
+        hipLaunchKernelGGL((level_scatter_kernel<true, NT, ITEMS, MINW>), dim3(n_chunks), dim3(NT), SC_SMEM, s,
+                           nodes, chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, dbg);
+    else
+        hipLaunchKernelGGL((level_scatter_kernel<false, NT, ITEMS, MINW>), dim3(n_chunks), dim3(NT), SC_SMEM, s,
+                           nodes, chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, dbg);
+}
 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
@@ -476,219 +498,328 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 {
     if (n_chunks == 0)
         return hipSuccess;
-    if (src_dna)
-        hipLaunchKernelGGL(level_scatter_kernel<true>, dim3(n_chunks), dim3(SC_THREADS), SC_SMEM, s, nodes,
-                           chunks, n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, tot);
-    else
-        hipLaunchKernelGGL(level_scatter_kernel<false>, dim3(n_chunks), dim3(SC_THREADS), SC_SMEM, s, nodes,
-                           chunks, n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, tot);
+    static int variant = -1;
+    if (variant < 0) {
+        const char *v = getenv("DNAGPU_SCATTER_VARIANT");
+        variant = v ? atoi(v) : 0;
+    }
+    const u64 mask = kmer_mask(k);
+    switch (variant) {
+    case 1: launch_scatter_variant<1024, 8, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
+    case 2: launch_scatter_variant<512, 16, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
+    case 3: launch_scatter_variant<512, 16, 2>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
+    default: launch_scatter_variant<1024, 8, 8>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
+    }
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// leaves: sort + run-length encode each leaf in LDS, emit groups in key order.
+// leaves: sort + run-length encode each leaf in LDS and append its groups to the output.
 //
-// Workgroups take leaves in ticket order (an atomic counter), so the chained scan below only ever
-// waits on workgroups that started earlier: no dependency on dispatch order or placement.  The
-// status word of a leaf is one self-validating 8-byte granule {flag:2, value:62} written and read
-// with relaxed agent-scope atomics (write-through / L1-bypassing); no other data is handed between
-// workgroups, so no fence is needed.
-constexpr u64 ST_AGG = (u64)1 << 62;     // value = this leaf's group count
-constexpr u64 ST_INC = (u64)2 << 62;     // value = group count of all leaves up to and including this
-constexpr u64 ST_VAL = ((u64)1 << 62) - 1;
-
-__global__ __launch_bounds__(LF_THREADS, 6) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
-                                                            const u64 *__restrict__ buf0,
-                                                            const u64 *__restrict__ buf1,
-                                                            u64 *__restrict__ status, u32 *__restrict__ ticket,
-                                                            u64 *__restrict__ out_keys,
-                                                            u64 *__restrict__ out_counts)
+// Persistent workgroups, static assignment (workgroup b takes leaves b, b + G, b + 2G, ...): while a
+// leaf is being sorted the next leaf's descriptor is already in scalar registers and, from the
+// middle of the leaf on, its keys are in flight into vector registers.
+//
+// Output placement: one returning atomic add per leaf on a 64-bit cursor hands the leaf a dense
+// range of the output arrays.  Workgroups never wait for each other (an ordered chained scan was
+// measured: on this chip its cross-XCD look-back cost 35-50 % of the kernel).  Leaves therefore land
+// in completion order; inside a leaf groups ascend, and the segment directory (seg_off/seg_cnt, in
+// leaf = key order) gives the globally ascending view that dnagpu_hist_download serves.
+template <int NT, int MINW>
+__global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
+                                                          const u64 *__restrict__ buf0,
+                                                          const u64 *__restrict__ buf1,
+                                                          unsigned long long *__restrict__ cursor,
+                                                          u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                          u64 *__restrict__ out_keys,
+                                                          u64 *__restrict__ out_counts, int dbg)
 {
+    constexpr int ITEMS = LEAF_CAP / NT;       // keys per thread
+    constexpr int BINS = NT * 4;               // counting-sort bins: one uint4 per thread
+    constexpr int SB = (NT == 1024) ? 12 : (NT == 512 ? 11 : 10);
+    constexpr int WAVES = NT / 64;
+    static_assert(ITEMS * WAVES == 64, "row/wave table must have 64 entries");
+    static_assert((1 << SB) == BINS, "bins");
+
     __shared__ __attribute__((aligned(16))) u64 A[LEAF_CAP];
-    __shared__ u32 H[LEAF_CAP + 8];          // bins -> exclusive offsets, later head positions
-    __shared__ u32 rowcnt[LF_ITEMS * (LF_THREADS / 64)];   // 64 entries: [row][wave]
-    __shared__ u32 wtmp[LF_THREADS / 64];
-    __shared__ u32 sh_ticket;
-    __shared__ u64 sh_excl;
+    __shared__ __attribute__((aligned(16))) u32 H[LEAF_CAP + 8];   // bins -> offsets; later head positions
+    __shared__ u32 rowcnt[64];                 // [row][wave] head counts -> exclusive offsets
+    __shared__ u32 wtmp[WAVES];
     __shared__ u32 sh_D;
+    __shared__ u64 sh_obase;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0)
-        sh_ticket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const u32 li = sh_ticket;
+    u32 li = blockIdx.x;
     if (li >= n_leaves)
         return;
-    const Node nd = leaves[li];
-    const u32 len = nd.len;
-    const int rem = (int)(nd.meta & 0xff);
-    u32 D = 0;                                 // groups in this leaf
-    const bool single = (len > 0) && (rem == 0 || (nd.meta & NODE_TERMINAL));
-
-    if (single) {
-        D = 1;
-    } else if (len > 0) {
+    Node nd = leaves[li];
+    u64 key[ITEMS];
+    if (nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL)) {
         const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + nd.start;
-        const int sb = rem < LF_SUB_BITS ? rem : LF_SUB_BITS;
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            u32 i = tid + j * NT;
+            key[j] = src[i < nd.len ? i : nd.len - 1];
+        }
+    }
+
+    for (;;) {
+        const u32 ln = li + gridDim.x;
+        const bool has_next = ln < n_leaves;
+        const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
+        __syncthreads();                           // A/H of the previous leaf are dead
+        const u32 len = nd.len;
+        const int rem = (int)(nd.meta & 0xff);
+        u32 D = 0;                                 // groups in this leaf
+        const bool single = (len > 0) && (rem == 0 || (nd.meta & NODE_TERMINAL));
+        const bool sorted_path = len > 0 && !single;
+        const int sb = rem < SB ? rem : SB;
         const int sshift = rem - sb;
-        const u32 S = 1u << sb, smask = S - 1;
-        for (u32 d = tid; d <= S; d += LF_THREADS)
-            H[d] = 0;
-        __syncthreads();
-        u64 key[LF_ITEMS];
-        u32 rank[LF_ITEMS];
+        const u32 smask = (1u << sb) - 1;
+        u64 hb[ITEMS];
+
+        if (sorted_path) {
+            reinterpret_cast<uint4 *>(H)[tid] = make_uint4(0, 0, 0, 0);
+            if (tid == 0)
+                H[BINS] = 0;
+            // Slots past the end of the leaf are not branched around: they carry an all-ones key,
+            // count in the extra bin BINS and so stage behind every real key.
 #pragma unroll
-        for (int j = 0; j < LF_ITEMS; j++) {
-            u32 i = tid + j * LF_THREADS;
-            key[j] = 0;
-            rank[j] = 0;
-            if (i < len) {
-                key[j] = src[i];
-                rank[j] = atomicAdd(&H[(u32)(key[j] >> sshift) & smask], 1u);
+            for (int j = 0; j < ITEMS; j++)
+                if (tid + j * NT >= len)
+                    key[j] = ~(u64)0;
+            __syncthreads();
+            u32 rank[ITEMS];
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                u32 i = tid + j * NT;
+                u32 b = i < len ? ((u32)(key[j] >> sshift) & smask) : (u32)BINS;
+                rank[j] = atomicAdd(&H[b], 1u);
             }
-        }
-        __syncthreads();
-        block_scan_inplace<LF_THREADS>(H, (int)S, wtmp);
-        if (tid == 0)
-            H[S] = len;
+            __syncthreads();
+            {   // exclusive scan of the bins, 4 consecutive bins per thread (16-byte LDS accesses)
+                uint4 v = reinterpret_cast<uint4 *>(H)[tid];
+                u32 sum = v.x + v.y + v.z + v.w, inc = sum;
 #pragma unroll
-        for (int j = 0; j < LF_ITEMS; j++) {
-            u32 i = tid + j * LF_THREADS;
-            if (i < len)
-                A[H[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
-        }
-        __syncthreads();
-        if (rem > sb) {
-            // exact rank inside each (small) bin: #smaller + #equal-before
-            u32 fin[LF_ITEMS];
+                for (int off = 1; off < 64; off <<= 1) {
+                    u32 t = __shfl_up(inc, off);
+                    if (lane >= off)
+                        inc += t;
+                }
+                if (lane == 63)
+                    wtmp[wave] = inc;
+                __syncthreads();
+                u32 base = inc - sum;
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                for (int w = 0; w < wv; w++)
+                    base += wtmp[w];
+                uint4 o;
+                o.x = base;
+                o.y = base + v.x;
+                o.z = o.y + v.y;
+                o.w = o.z + v.z;
+                reinterpret_cast<uint4 *>(H)[tid] = o;
+                if (tid == 0)
+                    H[BINS] = len;
+            }
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < LF_ITEMS; j++) {
-                u32 i = tid + j * LF_THREADS;
-                fin[j] = 0;
-                if (i < len) {
+            for (int j = 0; j < ITEMS; j++) {
+                u32 i = tid + j * NT;
+                u32 b = i < len ? ((u32)(key[j] >> sshift) & smask) : (u32)BINS;
+                A[H[b] + rank[j]] = key[j];
+            }
+            __syncthreads();
+            if (rem > sb && !(dbg & 1)) {
+                // exact rank inside each (small) bin: #smaller + #equal-before
+#pragma unroll
+                for (int j = 0; j < ITEMS; j++) {
+                    u32 i = tid + j * NT;
                     u64 kv = A[i];
                     key[j] = kv;
                     u32 b = (u32)(kv >> sshift) & smask;
-                    u32 b0 = H[b], b1 = H[b + 1];
-                    u32 r = b0;
+                    u32 b0 = H[b];
+                    u32 b1 = i < len ? H[b + 1] : b0;
+                    u32 r = i < len ? b0 : i;
 #pragma unroll 1
                     for (u32 m = b0; m < b1; m++) {
                         u64 o = A[m];
                         r += (o < kv) || (o == kv && m < i);
                     }
-                    fin[j] = r;
+                    rank[j] = r;
                 }
-            }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (int j = 0; j < LF_ITEMS; j++) {
-                u32 i = tid + j * LF_THREADS;
-                if (i < len)
-                    A[fin[j]] = key[j];
+                for (int j = 0; j < ITEMS; j++)
+                    A[rank[j]] = key[j];
+                __syncthreads();
             }
-            __syncthreads();
         }
-        // run heads in sorted order; row j = positions [j*LF_THREADS, (j+1)*LF_THREADS)
-        u64 hb[LF_ITEMS];
-#pragma unroll
-        for (int j = 0; j < LF_ITEMS; j++) {
-            u32 i = tid + j * LF_THREADS;
-            bool head = i < len && (i == 0 || A[i] != A[i - 1]);
-            hb[j] = __ballot(head);
-            if (lane == 0)
-                rowcnt[j * (LF_THREADS / 64) + wave] = (u32)__popcll(hb[j]);
-        }
-        __syncthreads();
-        if (wave == 0) {
-            u32 v = rowcnt[lane], inc = v;
-            for (int off = 1; off < 64; off <<= 1) {
-                u32 t = __shfl_up(inc, off);
-                if (lane >= off)
-                    inc += t;
-            }
-            rowcnt[lane] = inc - v;
-            if (lane == 63)
-                sh_D = inc;
-        }
-        __syncthreads();
-        D = sh_D;
-        const u64 below = ((u64)1 << lane) - 1;
-#pragma unroll
-        for (int j = 0; j < LF_ITEMS; j++)
-            if ((hb[j] >> lane) & 1)
-                H[rowcnt[j * (LF_THREADS / 64) + wave] + (u32)__popcll(hb[j] & below)] = tid + j * LF_THREADS;
-        if (tid == 0)
-            H[D] = len;
-        // (H as bin offsets is dead: every read of it happened before the barriers above)
-    }
 
-    // ---- chained scan over leaves: exclusive group count of all earlier leaves
-    if (wave == 0) {
-        if (lane == 0)
-            st_agent(&status[li], (li == 0 ? ST_INC : ST_AGG) | (u64)D);
-        u64 excl = 0;
-        if (li > 0) {
-            long long j = (long long)li - 1;
-            u32 spins = 0;
-            for (;;) {
-                long long idx = j - lane;
-                u64 sv = idx >= 0 ? ld_agent(&status[idx]) : ST_INC;
-                u32 flag = (u32)(sv >> 62);
-                if (__any(flag == 0)) {
-                    // every earlier ticket is held by a running or finished workgroup, so this wait
-                    // ends; the bound only turns a logic error into a reported failure, not a hang
-                    if (++spins > (1u << 24)) {
-                        if (lane == 0)
-                            atomicOr(ticket + 1, 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                u64 incmask = __ballot(flag == 2);
-                u64 val = sv & ST_VAL;
-                if (incmask) {
-                    int firstinc = __ffsll((long long)incmask) - 1;
-                    if (lane > firstinc)
-                        val = 0;
-                }
-                for (int off = 32; off > 0; off >>= 1)
-                    val += __shfl_down(val, off);
-                val = __shfl(val, 0);
-                excl += val;
-                if (incmask)
-                    break;
-                j -= 64;
+        // ---- the sort no longer needs key[]: start the next leaf's loads (they land while this
+        // leaf's heads, placement and output run)
+        if (has_next && nn.len > 0 && (nn.meta & 0xff) != 0 && !(nn.meta & NODE_TERMINAL)) {
+            const u64 *__restrict__ nsrc = ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start;
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                u32 i = tid + j * NT;
+                key[j] = nsrc[i < nn.len ? i : nn.len - 1];
             }
-            if (lane == 0)
-                st_agent(&status[li], ST_INC | (excl + D));
         }
-        if (lane == 0)
-            sh_excl = excl;
-    }
-    __syncthreads();
-    const u64 obase = sh_excl;
-    if (single) {
+
+        if (single) {
+            D = 1;
+        } else if (sorted_path) {
+            // run heads in sorted order; row j = positions [j*NT, (j+1)*NT)
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                u32 i = tid + j * NT;
+                bool head = (i < len) & ((i == 0) | (A[i] != A[i ? i - 1 : 0]));
+                hb[j] = __ballot(head);
+                if (lane == 0)
+                    rowcnt[j * WAVES + wave] = (u32)__popcll(hb[j]);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                u32 v = rowcnt[lane], inc = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    u32 t = __shfl_up(inc, off);
+                    if (lane >= off)
+                        inc += t;
+                }
+                rowcnt[lane] = inc - v;
+                if (lane == 63)
+                    sh_D = inc;
+            }
+            __syncthreads();
+            D = sh_D;
+        }
+        // ---- placement: one atomic per leaf (its latency overlaps the head-position fill below)
         if (tid == 0) {
-            out_keys[obase] = nd.prefix;
-            out_counts[obase] = len;
+            u64 ob = 0;
+            if (D > 0)
+                ob = (dbg & 2) ? (u64)nd.start : (u64)atomicAdd(cursor, (unsigned long long)D);
+            sh_obase = ob;
+            seg_off[li] = ob;
+            seg_cnt[li] = D;
         }
-    } else {
-        for (u32 q = tid; q < D; q += LF_THREADS) {
-            u32 p = H[q];
-            out_keys[obase + q] = A[p];
-            out_counts[obase + q] = H[q + 1] - p;
+        if (sorted_path) {
+            const u64 below = ((u64)1 << lane) - 1;
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                if ((hb[j] >> lane) & 1)
+                    H[rowcnt[j * WAVES + wave] + (u32)__popcll(hb[j] & below)] = tid + j * NT;
+            if (tid == 0)
+                H[D] = len;
+            // (H as bin offsets is dead: every read of it happened before the barriers above)
         }
+        __syncthreads();
+        const u64 obase = sh_obase;
+        if (!(dbg & 4)) {
+            if (single) {
+                if (tid == 0) {
+                    out_keys[obase] = nd.prefix;
+                    out_counts[obase] = len;
+                }
+            } else {
+                for (u32 q2 = tid; q2 < D; q2 += NT) {
+                    u32 p = H[q2];
+                    out_keys[obase + q2] = A[p];
+                    out_counts[obase + q2] = H[q2 + 1] - p;
+                }
+            }
+        }
+        if (!has_next)
+            break;
+        li = ln;
+        nd = nn;
     }
 }
 
+static u32 leaves_grid(u32 n_leaves, int per_cu)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0)
+            n_cu = 256;
+    }
+    u32 g = (u32)n_cu * (u32)per_cu;
+    return n_leaves < g ? n_leaves : g;
+}
+
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
-                         u64 *status, u32 *ticket, u64 *out_keys, u64 *out_counts, hipStream_t s)
+                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u64 *out_counts, hipStream_t s)
 {
     if (n_leaves == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(leaves_kernel, dim3(n_leaves), dim3(LF_THREADS), 0, s, leaves, n_leaves, buf0, buf1,
-                       status, ticket, out_keys, out_counts);
+    static int dbg = -1, variant = 0, mult = 1;
+    if (dbg < 0) {
+        const char *e = getenv("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
+        dbg = e ? atoi(e) : 0;
+        const char *v = getenv("DNAGPU_LEAVES_VARIANT");
+        variant = v ? atoi(v) : 1;                       // 512 threads x 8 keys, 3 workgroups per CU
+        const char *m = getenv("DNAGPU_LEAVES_GRIDMULT");
+        mult = m ? atoi(m) : 1;
+        if (mult < 1)
+            mult = 1;
+    }
+    unsigned long long *cur = reinterpret_cast<unsigned long long *>(cursor);
+    if (variant == 1)
+        hipLaunchKernelGGL((leaves_kernel<512, 6>), dim3(leaves_grid(n_leaves, 3 * mult)), dim3(512), 0, s, leaves,
+                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+    else if (variant == 2)
+        hipLaunchKernelGGL((leaves_kernel<1024, 4>), dim3(leaves_grid(n_leaves, 1 * mult)), dim3(1024), 0, s, leaves,
+                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+    else if (variant == 3)
+        hipLaunchKernelGGL((leaves_kernel<512, 4>), dim3(leaves_grid(n_leaves, 2 * mult)), dim3(512), 0, s, leaves,
+                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+    else
+        hipLaunchKernelGGL((leaves_kernel<1024, 8>), dim3(leaves_grid(n_leaves, 2 * mult)), dim3(1024), 0, s, leaves,
+                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ascending view of a histogram: leaf l (leaves are in key order) holds seg_cnt[l] groups at
+// seg_off[l]; seg_pre is the exclusive scan of seg_cnt.  Copies groups [first, first+count) of the
+// ascending order into dst arrays (index 0 = group `first`).  One workgroup per leaf.
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const u64 *__restrict__ seg_off,
+                                                            const u32 *__restrict__ seg_cnt,
+                                                            const u32 *__restrict__ seg_pre, u32 n_leaves,
+                                                            u64 first, u64 count, const u64 *__restrict__ keys,
+                                                            const u64 *__restrict__ counts,
+                                                            u64 *__restrict__ dst_keys, u64 *__restrict__ dst_counts)
+{
+    const u32 l = blockIdx.x;
+    if (l >= n_leaves)
+        return;
+    const u64 p0 = seg_pre[l], c = seg_cnt[l];
+    if (c == 0 || p0 + c <= first || p0 >= first + count)
+        return;
+    const u64 lo = p0 < first ? first - p0 : 0;
+    const u64 hi = p0 + c > first + count ? first + count - p0 : c;
+    const u64 so = seg_off[l];
+    for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        if (dst_keys)
+            dst_keys[p0 + i - first] = keys[so + i];
+        if (dst_counts)
+            dst_counts[p0 + i - first] = counts[so + i];
+    }
+}
+
+hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
+                                u64 first, u64 count, const u64 *keys, const u64 *counts, u64 *dst_keys,
+                                u64 *dst_counts, hipStream_t s)
+{
+    if (n_leaves == 0 || count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(n_leaves), dim3(256), 0, s, seg_off, seg_cnt, seg_pre, n_leaves,
+                       first, count, keys, counts, dst_keys, dst_counts);
     return hipGetLastError();
 }
 

@@ -94,10 +94,15 @@ struct dnagpu_dna {
 };
 
 struct dnagpu_hist {
-    u64 *keys;
+    u64 *keys;        // n_distinct groups, dense; stored leaf by leaf in completion order
     u64 *counts;
     u64 n_distinct;
     u64 total;
+    // segment directory: leaf l (leaves are in ascending key order) = seg_cnt[l] groups at seg_off[l]
+    u64 *seg_off;
+    u32 *seg_cnt;
+    u32 *seg_pre;     // exclusive scan of seg_cnt, built on first ordered download
+    u32 n_segs;
 };
 
 static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
@@ -812,7 +817,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
 {
     if (n > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
-    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, n};
+    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, n, nullptr, nullptr, nullptr, 0};
     if (!h)
         return DNAGPU_ERR_OOM;
     if (n == 0) {
@@ -825,47 +830,51 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         PoolScope ps(ctx);
         TreeResult tr;
         rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr);
-        u64 *status = nullptr;
-        u32 *ticket = nullptr;
+        u64 *cursor = nullptr, *seg_off = nullptr;
+        u32 *seg_cnt = nullptr;
         u64 *ok = nullptr, *oc = nullptr;
         // a k-mer of k bases has at most 4^k distinct values
         u64 cap = n;
         if (k < 16)
             cap = std::min<u64>(n, (u64)1 << (2 * k));
-        if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &status);
-        if (rc == DNAGPU_OK) rc = ps.alloc(2, &ticket);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &cursor);
+        if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &seg_off);
+        if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &seg_cnt);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
         hipError_t e = hipSuccess;
-        u64 last = 0;
-        u32 tick[2] = {0, 0};
+        u64 total_groups = 0;
         if (rc == DNAGPU_OK) {
             prof_mark(ctx, "leaves");
-            e = hipMemsetAsync(status, 0, (size_t)tr.n_nodes * 8, ctx->stream);
-            if (e == hipSuccess) e = hipMemsetAsync(ticket, 0, 8, ctx->stream);
+            e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
-                e = launch_leaves(tr.nodes, tr.n_nodes, tr.buf0, tr.buf1, status, ticket, ok, oc, ctx->stream);
+                e = launch_leaves(tr.nodes, tr.n_nodes, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt, ok, oc,
+                                  ctx->stream);
             prof_mark(ctx, "end");
             if (e == hipSuccess)
-                e = hipMemcpyAsync(&last, status + (tr.n_nodes - 1), 8, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(tick, ticket, 8, hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) {
                 set_err("leaves: %s", hipGetErrorString(e));
                 rc = DNAGPU_ERR_HIP;
-            } else if (tick[1] != 0) {
-                set_err("leaves: chained scan timed out");
+            } else if (total_groups > cap) {
+                set_err("leaves: %llu groups exceed the output capacity %llu", (unsigned long long)total_groups,
+                        (unsigned long long)cap);
                 rc = DNAGPU_ERR_INTERNAL;
             }
         }
         if (rc == DNAGPU_OK) {
-            h->n_distinct = last & (((u64)1 << 62) - 1);
+            h->n_distinct = total_groups;
             h->keys = ok;
             h->counts = oc;
+            h->seg_off = seg_off;
+            h->seg_cnt = seg_cnt;
+            h->n_segs = tr.n_nodes;
             ps.release(ok);
             ps.release(oc);
+            ps.release(seg_off);
+            ps.release(seg_cnt);
         }
     }
     prof_end(ctx);
@@ -902,21 +911,52 @@ extern "C" uint64_t dnagpu_hist_total(const dnagpu_hist *h) { return h ? h->tota
 extern "C" const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h) { return h ? h->keys : nullptr; }
 extern "C" const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
 
-extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
+// Ascending-key order through the segment directory: groups are gathered on the device into a
+// staging window, then copied to the host.
+extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uint64_t first, uint64_t count,
                                     uint64_t *keys, uint64_t *counts)
 {
+    dnagpu_hist *h = const_cast<dnagpu_hist *>(h_c);
     if (!ctx || !h)
         return DNAGPU_ERR_BAD_ARG;
     if (first > h->n_distinct || count > h->n_distinct - first)
         return DNAGPU_ERR_BAD_ARG;
-    if (count == 0)
+    if (count == 0 || (!keys && !counts))
         return DNAGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    if (!h->seg_pre) {
+        u32 *pre = nullptr, *tmp = nullptr;
+        RC_TRY(pool_alloc_t(ctx, (size_t)h->n_segs + 1, &pre));
+        int rc = ps.alloc((size_t)scan_tmp_words(h->n_segs), &tmp);
+        hipError_t e = rc == DNAGPU_OK ? launch_scan_u32(h->seg_cnt, pre, h->n_segs, tmp, pre + h->n_segs, ctx->stream)
+                                       : hipSuccess;
+        if (rc != DNAGPU_OK || e != hipSuccess) {
+            pool_free(ctx, pre);
+            if (rc == DNAGPU_OK) {
+                set_err("segment scan: %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            }
+            return rc;
+        }
+        h->seg_pre = pre;
+    }
+    const u64 BATCH = (u64)1 << 25;            // 32 Mi groups = 2 x 256 MiB staging
+    u64 *sk = nullptr, *sc = nullptr;
     if (keys)
-        HIP_TRY(hipMemcpyAsync(keys, h->keys + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RC_TRY(ps.alloc((size_t)std::min(count, BATCH), &sk));
     if (counts)
-        HIP_TRY(hipMemcpyAsync(counts, h->counts + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+        RC_TRY(ps.alloc((size_t)std::min(count, BATCH), &sc));
+    for (u64 done = 0; done < count; done += BATCH) {
+        u64 nb = std::min(BATCH, count - done);
+        HIP_TRY(launch_gather_sorted(h->seg_off, h->seg_cnt, h->seg_pre, h->n_segs, first + done, nb, h->keys,
+                                     h->counts, sk, sc, ctx->stream));
+        if (keys)
+            HIP_TRY(hipMemcpyAsync(keys + done, sk, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (counts)
+            HIP_TRY(hipMemcpyAsync(counts + done, sc, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return DNAGPU_OK;
 }
 
@@ -947,6 +987,9 @@ extern "C" void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h)
     if (ctx) {
         pool_free(ctx, h->keys);
         pool_free(ctx, h->counts);
+        pool_free(ctx, h->seg_off);
+        pool_free(ctx, h->seg_cnt);
+        pool_free(ctx, h->seg_pre);
     }
     delete h;
 }

@@ -85,10 +85,14 @@ hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *tot, Node 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
                                 const u32 *hist, const u32 *tot, hipStream_t s);
-// leaves -> (key, count) groups in key order.  status: n_leaves u64 zeroed; ticket: two u32 zeroed
-// (ticket[0] = next leaf to take, ticket[1] = error flag set if the chained scan gave up waiting).
+// leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
+// (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
-                         u64 *status, u32 *ticket, u64 *out_keys, u64 *out_counts, hipStream_t s);
+                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u64 *out_counts, hipStream_t s);
+// groups [first, first+count) of the ascending-key view -> dst arrays
+hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
+                                u64 first, u64 count, const u64 *keys, const u64 *counts, u64 *dst_keys,
+                                u64 *dst_counts, hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();

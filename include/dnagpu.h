@@ -132,8 +132,10 @@ int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k
 typedef struct dnagpu_hist dnagpu_hist;
 
 /* Groups rows [first, first+count) of generate_kmers(dna,k) by key.  The result lives in device
- * memory: n_distinct (key, count) pairs, keys ascending as uint64 (PostgreSQL leaves group order
- * unspecified; ascending is this library's canonical order).  At most 2^32-1 rows per call. */
+ * memory: n_distinct (key, count) pairs in two dense arrays.  Group order in those arrays is
+ * unspecified, as it is in PostgreSQL (the arrays hold key-range segments in the order the GPU
+ * finished them, keys ascending inside a segment); dnagpu_hist_download serves the groups in
+ * ascending key order through the segment directory.  At most 2^32-1 rows per call. */
 int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                        uint64_t first, uint64_t count, dnagpu_hist **out);
 /* Same over an arbitrary array of n keys of k bases already in device memory.  dev_keys is used as
@@ -144,7 +146,8 @@ uint64_t dnagpu_hist_distinct(const dnagpu_hist *h);   /* count(*) over groups  
 uint64_t dnagpu_hist_total(const dnagpu_hist *h);      /* sum(count)                              */
 const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h);
 const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
-/* Copies groups [first, first+count) to host arrays (either may be NULL). */
+/* Copies groups [first, first+count) of the ASCENDING-KEY order to host arrays (either may be
+ * NULL). */
 int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
                          uint64_t *keys, uint64_t *counts);
 /* total = sum(count), unique = count(*) FILTER (WHERE count = 1) (test.sql:112-114), checksum =
@@ -160,7 +163,7 @@ void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h);
  * (contiguous, ascending key ranges).  *dev_keys receives a device buffer of `count` keys grouped
  * by owner, owner_offsets[0..n_owners] the group boundaries.  Free with dnagpu_buffer_free.
  * Step 2 (caller): exchange the groups.  Step 3: dnagpu_count_keys on what was received; the
- * concatenation of the owners' results in owner order is the global result, keys ascending. */
+ * concatenation of the owners' downloads in owner order is the global result, keys ascending. */
 int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                            uint64_t first, uint64_t count, int n_owners,
                            uint64_t **dev_keys, uint64_t *owner_offsets);

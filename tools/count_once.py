@@ -1,0 +1,17 @@
+"""Runs `iters` counts of k over n synthetic bases (for rocprofv3 runs). Usage: count_once.py n k iters [motif]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+n, k, iters = int(float(sys.argv[1])), int(sys.argv[2]), int(sys.argv[3])
+motif = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+with pkg.Context(0) as ctx:
+    ctx.set_profiling(True)
+    d = ctx.synth(0xD2A0003, n, motif)
+    for _ in range(iters):
+        h = ctx.count_kmers(d, k)
+        print(h.distinct, [(a, round(b, 3)) for a, b in ctx.last_phase_times()], flush=True)
+        h.free()
