@@ -471,6 +471,140 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// level_scatter with aligned write combining (the default).
+//
+// Measured on MI355X (tools/microbench/scatter_runs.hip): scattered 8-byte-granular runs of 64 B
+// reach 0.84 TB/s, the same bytes as 64-byte ALIGNED units 2.7 TB/s.  So a digit's keys leave the
+// tile only in whole 64-byte units of its destination: after staging, digit d flushes the keys up
+// to the last 64-byte boundary of its output stream and carries the rest (< 8 keys) into the next
+// tile.  Thread d owns digit d's carry in registers (R <= 1024 = workgroup size), so the LDS holds
+// one 16,384-key stage (128 KB) plus three small tables; every tile takes T - 7R new keys.
+constexpr int WC_THREADS = 1024;
+constexpr int WC_ITEMS = 16;
+constexpr int WC_TILE = WC_THREADS * WC_ITEMS;          // 16384 staged keys
+constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 3 + 16 * 4;
+
+template <bool SRC_DNA>
+__global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
+                                                                         const Chunk *__restrict__ chunks,
+                                                                         u32 n_chunks,
+                                                                         const u64 *__restrict__ words, u64 n_words,
+                                                                         u64 first, u64 mask,
+                                                                         u64 *__restrict__ buf0,
+                                                                         u64 *__restrict__ buf1,
+                                                                         const u32 *__restrict__ hist,
+                                                                         const u32 *__restrict__ tot)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *stage = reinterpret_cast<u64 *>(smem);                          // WC_TILE keys
+    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);     // R + 2 (counts, then offsets)
+    u32 *offs = excl + ROW_STRIDE + 8;                                   // next output index per digit
+    u32 *flsh = offs + ROW_STRIDE + 8;                                   // keys digit d flushes this tile
+    u32 *wtmp = flsh + ROW_STRIDE + 8;                                   // 16
+
+    if (blockIdx.x >= n_chunks)
+        return;
+    const Chunk ch = chunks[blockIdx.x];
+    const Node nd = nodes[ch.node];
+    const int bits = (int)nd.split;
+    const int rem = (int)(nd.meta & 0xff);
+    if (bits == rem)
+        return;                                   // terminal split: nothing moves
+    const int shift = rem - bits;
+    const u32 R = 1u << bits, dmask = R - 1;
+    const u32 tid = threadIdx.x;
+    const u64 origin = (u64)nd.start + ch.off;
+    const u64 *__restrict__ src = SRC_DNA ? nullptr : (((nd.meta & NODE_BUF) ? buf1 : buf0) + origin);
+    u64 *__restrict__ dst = SRC_DNA ? buf0 : ((nd.meta & NODE_BUF) ? buf0 : buf1);
+    const u32 newcap = (u32)WC_TILE - 7u * R;     // new keys per tile; the rest of the stage is carry room
+    const u32 abase = (u32)((reinterpret_cast<uintptr_t>(dst) >> 3) & 7u);   // 64-byte phase of the buffer
+    // dna root: thread t extracts `per` consecutive windows (<= 16, three packed words), all threads busy
+    const u32 per = (newcap + WC_THREADS - 1) / WC_THREADS;
+
+    if (tid < R)
+        offs[tid] = hist[(u64)blockIdx.x * ROW_STRIDE + tid] + tot[(u64)nd.chunk_base * ROW_STRIDE + tid];
+    u64 carry[7];
+    u32 ccnt = 0;
+#pragma unroll
+    for (int c = 0; c < 7; c++)
+        carry[c] = 0;
+
+    for (u32 t0 = 0; t0 < ch.len; t0 += newcap) {
+        const u32 tn = ch.len - t0 < newcap ? ch.len - t0 : newcap;   // new keys of this tile
+        const bool last = t0 + tn >= ch.len;
+        // digit counters start at the carried count, so ranks of new keys land behind the carry
+        if (tid < R)
+            excl[tid] = ccnt;
+        if (tid == 0)
+            excl[R] = 0;
+        u64 key[WC_ITEMS];
+        if (SRC_DNA) {
+            Win16 w = win16_load(words, n_words, first + origin + t0 + tid * per);
+#pragma unroll
+            for (int j = 0; j < WC_ITEMS; j++)
+                key[j] = win16_key(w, j, mask);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WC_ITEMS; j++) {
+                u32 i = tid + j * WC_THREADS;
+                key[j] = src[t0 + (i < tn ? i : tn - 1)];
+            }
+        }
+        __syncthreads();
+        u32 pos[WC_ITEMS];
+#pragma unroll
+        for (int j = 0; j < WC_ITEMS; j++) {
+            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
+            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;     // slots past the end: extra digit R
+            pos[j] = atomicAdd(&excl[d], 1u);
+        }
+        __syncthreads();
+        block_scan_inplace<WC_THREADS>(excl, (int)R + 1, wtmp);       // excl[R] = staged real keys
+#pragma unroll
+        for (int j = 0; j < WC_ITEMS; j++) {
+            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
+            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
+            u32 p = excl[d] + pos[j];
+            if (p < (u32)WC_TILE)                   // (padding slots beyond the stage are dropped)
+                stage[p] = key[j];
+        }
+        u32 f = 0, m = 0, e0 = 0;
+        if (tid < R) {
+            e0 = excl[tid];
+            m = excl[tid + 1] - e0;                 // carried + new keys of this digit
+#pragma unroll
+            for (int c = 0; c < 7; c++)
+                if ((u32)c < ccnt)
+                    stage[e0 + c] = carry[c];
+            const u32 o = offs[tid];
+            const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
+            f = last ? m : (m >= tail ? m - tail : 0u);
+            flsh[tid] = f;
+        }
+        __syncthreads();
+        const u32 staged = excl[R];
+#pragma unroll 2
+        for (u32 i = tid; i < staged; i += WC_THREADS) {
+            u64 kv = stage[i];
+            u32 d = (u32)(kv >> shift) & dmask;
+            u32 j = i - excl[d];
+            if (j < flsh[d])
+                dst[(u64)offs[d] + j] = kv;
+        }
+        if (tid < R) {
+            ccnt = m - f;                           // <= 7
+#pragma unroll
+            for (int c = 0; c < 7; c++)
+                if ((u32)c < ccnt)
+                    carry[c] = stage[e0 + f + c];
+        }
+        __syncthreads();
+        if (tid < R)
+            offs[tid] += f;
+    }
+}
+
 constexpr size_t SC_SMEM = (size_t)SC_TILE * 8 + (size_t)(ROW_STRIDE + 4) * 4 + (size_t)ROW_STRIDE * 4 + 16 * 4;
 
 template <int NT, int ITEMS, int MINW>
@@ -501,9 +635,29 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
     static int variant = -1;
     if (variant < 0) {
         const char *v = getenv("DNAGPU_SCATTER_VARIANT");
-        variant = v ? atoi(v) : 0;
+        // 1 = 8192-key tile, two workgroups per CU (fastest at 3 Gbase today); 0 = 16384-key tile with
+        // aligned 64-byte write combining (all-64B write requests, but one workgroup per CU: it wins
+        // only where R <= 512)
+        variant = v ? atoi(v) : 1;
     }
     const u64 mask = kmer_mask(k);
+    if (variant == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_SMEM);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_SMEM);
+            attr_set = true;
+        }
+        if (src_dna)
+            hipLaunchKernelGGL(level_scatter_wc_kernel<true>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
+                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot);
+        else
+            hipLaunchKernelGGL(level_scatter_wc_kernel<false>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
+                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot);
+        return hipGetLastError();
+    }
     switch (variant) {
     case 1: launch_scatter_variant<1024, 8, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
     case 2: launch_scatter_variant<512, 16, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
