@@ -41,6 +41,28 @@ template <int NT>
 __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n <= NT) {                          // one element per thread: no per-thread loops
+        u32 v = tid < n ? arr[tid] : 0, inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 t = __shfl_up(inc, off);
+            if (lane >= off)
+                inc += t;
+        }
+        if (lane == 63)
+            wtmp[wave] = inc;
+        __syncthreads();
+        const int wv1 = __builtin_amdgcn_readfirstlane(wave);
+        u32 wbase1 = 0, total1 = 0;
+        for (int w = 0; w < wv1; w++)
+            wbase1 += wtmp[w];
+        for (int w = 0; w < NT / 64; w++)
+            total1 += wtmp[w];
+        if (tid < n)
+            arr[tid] = wbase1 + inc - v;
+        __syncthreads();
+        return total1;
+    }
     const int per = (n + NT - 1) / NT;
     const int b = tid * per;
     const int e = (b + per < n) ? b + per : n;
@@ -442,16 +464,17 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
-            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
-            pos[j] = atomicAdd(&excl[d], 1u);
+            pos[j] = 0;
+            if (i < tn)
+                pos[j] = atomicAdd(&excl[(u32)(key[j] >> shift) & dmask], 1u);
         }
         __syncthreads();
         block_scan_inplace<NT>(excl, (int)R + 1, wtmp);      // excl[R] = tn afterwards
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
-            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
-            stage[excl[d] + pos[j]] = key[j];
+            if (i < tn)
+                stage[excl[(u32)(key[j] >> shift) & dmask] + pos[j]] = key[j];
         }
         __syncthreads();
 #pragma unroll 2
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 constexpr int WC_THREADS = 1024;
 constexpr int WC_ITEMS = 16;
 constexpr int WC_TILE = WC_THREADS * WC_ITEMS;          // 16384 staged keys
-constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 3 + 16 * 4;
+constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 4 + 32 * 4;
 
 template <bool SRC_DNA>
 __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
@@ -494,14 +517,14 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
                                                                          u64 *__restrict__ buf0,
                                                                          u64 *__restrict__ buf1,
                                                                          const u32 *__restrict__ hist,
-                                                                         const u32 *__restrict__ tot)
+                                                                         const u32 *__restrict__ tot, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *stage = reinterpret_cast<u64 *>(smem);                          // WC_TILE keys
     u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);     // R + 2 (counts, then offsets)
     u32 *offs = excl + ROW_STRIDE + 8;                                   // next output index per digit
-    u32 *flsh = offs + ROW_STRIDE + 8;                                   // keys digit d flushes this tile
-    u32 *wtmp = flsh + ROW_STRIDE + 8;                                   // 16
+    u32 *flsh = offs + ROW_STRIDE + 8;                                   // {delta, limit} per digit (uint2)
+    u32 *wtmp = flsh + 2 * (ROW_STRIDE + 8);                             // 16 + carry total
 
     if (blockIdx.x >= n_chunks)
         return;
@@ -517,58 +540,71 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     const u64 origin = (u64)nd.start + ch.off;
     const u64 *__restrict__ src = SRC_DNA ? nullptr : (((nd.meta & NODE_BUF) ? buf1 : buf0) + origin);
     u64 *__restrict__ dst = SRC_DNA ? buf0 : ((nd.meta & NODE_BUF) ? buf0 : buf1);
-    const u32 newcap = (u32)WC_TILE - 7u * R;     // new keys per tile; the rest of the stage is carry room
     const u32 abase = (u32)((reinterpret_cast<uintptr_t>(dst) >> 3) & 7u);   // 64-byte phase of the buffer
-    // dna root: thread t extracts `per` consecutive windows (<= 16, three packed words), all threads busy
-    const u32 per = (newcap + WC_THREADS - 1) / WC_THREADS;
+    u32 *sh_carry = wtmp + 16;                    // carried keys in total (sets the next tile's size)
 
     if (tid < R)
         offs[tid] = hist[(u64)blockIdx.x * ROW_STRIDE + tid] + tot[(u64)nd.chunk_base * ROW_STRIDE + tid];
+    if (tid == 0)
+        *sh_carry = 0;
     u64 carry[7];
     u32 ccnt = 0;
 #pragma unroll
     for (int c = 0; c < 7; c++)
         carry[c] = 0;
 
-    for (u32 t0 = 0; t0 < ch.len; t0 += newcap) {
-        const u32 tn = ch.len - t0 < newcap ? ch.len - t0 : newcap;   // new keys of this tile
+    // A tile = the carried keys + as many new keys as still fit the 16,384-slot stage.  The new keys
+    // of tile t+1 are requested as soon as tile t is staged, so their latency hides behind tile t's
+    // write-out (one workgroup per CU: nobody else would hide it).
+    u32 t0 = 0;
+    u32 tn = ch.len < (u32)WC_TILE ? ch.len : (u32)WC_TILE;
+    u32 per = (tn + WC_THREADS - 1) / WC_THREADS;         // dna root: consecutive windows per thread
+    u64 key[WC_ITEMS];
+    Win16 w;
+    if (SRC_DNA) {
+        w = win16_load(words, n_words, first + origin + tid * per);
+    } else {
+#pragma unroll
+        for (int j = 0; j < WC_ITEMS; j++) {
+            u32 i = tid + j * WC_THREADS;
+            key[j] = src[i < tn ? i : tn - 1];
+        }
+    }
+
+    for (;;) {
         const bool last = t0 + tn >= ch.len;
         // digit counters start at the carried count, so ranks of new keys land behind the carry
         if (tid < R)
             excl[tid] = ccnt;
         if (tid == 0)
             excl[R] = 0;
-        u64 key[WC_ITEMS];
         if (SRC_DNA) {
-            Win16 w = win16_load(words, n_words, first + origin + t0 + tid * per);
 #pragma unroll
             for (int j = 0; j < WC_ITEMS; j++)
                 key[j] = win16_key(w, j, mask);
-        } else {
-#pragma unroll
-            for (int j = 0; j < WC_ITEMS; j++) {
-                u32 i = tid + j * WC_THREADS;
-                key[j] = src[t0 + (i < tn ? i : tn - 1)];
-            }
         }
         __syncthreads();
         u32 pos[WC_ITEMS];
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
-            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;     // slots past the end: extra digit R
-            pos[j] = atomicAdd(&excl[d], 1u);
+            pos[j] = 0;
+            if (i < tn)                             // (no dummy digit: same-address LDS atomics serialise)
+                pos[j] = atomicAdd(&excl[(u32)(key[j] >> shift) & dmask], 1u);
         }
         __syncthreads();
-        block_scan_inplace<WC_THREADS>(excl, (int)R + 1, wtmp);       // excl[R] = staged real keys
+        {
+            const u32 staged_total = block_scan_inplace<WC_THREADS>(excl, (int)R, wtmp);
+            if (tid == 0)
+                excl[R] = staged_total;               // (visible after the barrier below)
+        }
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
-            u32 d = i < tn ? ((u32)(key[j] >> shift) & dmask) : R;
-            u32 p = excl[d] + pos[j];
-            if (p < (u32)WC_TILE)                   // (padding slots beyond the stage are dropped)
-                stage[p] = key[j];
+            if (i < tn)
+                stage[excl[(u32)(key[j] >> shift) & dmask] + pos[j]] = key[j];
         }
+        __syncthreads();                            // excl[R] (thread 0) and every stage write are visible
         u32 f = 0, m = 0, e0 = 0;
         if (tid < R) {
             e0 = excl[tid];
@@ -580,17 +616,40 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
             const u32 o = offs[tid];
             const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
             f = last ? m : (m >= tail ? m - tail : 0u);
-            flsh[tid] = f;
+            // write-out: staged slot i of digit d goes to dst[i + delta] while i < limit
+            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 + f);
+        }
+        {   // total carried into the next tile
+            u32 cn = m - f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                cn += __shfl_down(cn, off);
+            if ((tid & 63) == 0 && cn)
+                atomicAdd(sh_carry, cn);
         }
         __syncthreads();
+        const u32 t0n = t0 + tn;
+        const u32 room = (u32)WC_TILE - *sh_carry;
+        const u32 tnn = ch.len - t0n < room ? ch.len - t0n : room;
+        if (tnn > 0) {                              // request the next tile's keys now
+            per = (tnn + WC_THREADS - 1) / WC_THREADS;
+            if (SRC_DNA) {
+                w = win16_load(words, n_words, first + origin + t0n + tid * per);
+            } else {
+#pragma unroll
+                for (int j = 0; j < WC_ITEMS; j++) {
+                    u32 i = tid + j * WC_THREADS;
+                    key[j] = src[t0n + (i < tnn ? i : tnn - 1)];
+                }
+            }
+        }
         const u32 staged = excl[R];
 #pragma unroll 2
         for (u32 i = tid; i < staged; i += WC_THREADS) {
             u64 kv = stage[i];
-            u32 d = (u32)(kv >> shift) & dmask;
-            u32 j = i - excl[d];
-            if (j < flsh[d])
-                dst[(u64)offs[d] + j] = kv;
+            uint2 dl = reinterpret_cast<const uint2 *>(flsh)[(u32)(kv >> shift) & dmask];
+            if (i < dl.y && !(dbg & 1))
+                dst[(u64)(u32)(i + dl.x)] = kv;
         }
         if (tid < R) {
             ccnt = m - f;                           // <= 7
@@ -602,6 +661,12 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
         __syncthreads();
         if (tid < R)
             offs[tid] += f;
+        if (tid == 0)
+            *sh_carry = 0;
+        if (tnn == 0)
+            break;
+        t0 = t0n;
+        tn = tnn;
     }
 }
 
@@ -635,10 +700,10 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
     static int variant = -1;
     if (variant < 0) {
         const char *v = getenv("DNAGPU_SCATTER_VARIANT");
-        // 1 = 8192-key tile, two workgroups per CU (fastest at 3 Gbase today); 0 = 16384-key tile with
-        // aligned 64-byte write combining (all-64B write requests, but one workgroup per CU: it wins
-        // only where R <= 512)
-        variant = v ? atoi(v) : 1;
+        // 0 = 16384-key tile with aligned 64-byte write combining, next tile prefetched (every write
+        // request a full 64 B; one workgroup per CU); 1.. = 8192-key tile without combining (two
+        // workgroups per CU).  Both measure 16-18 ms per level at 3 Gbase; 0 is faster for R <= 512.
+        variant = v ? atoi(v) : 0;
     }
     const u64 mask = kmer_mask(k);
     if (variant == 0) {
@@ -650,12 +715,17 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_SMEM);
             attr_set = true;
         }
+        static int wdbg = -1;
+        if (wdbg < 0) {
+            const char *e = getenv("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results invalid when set
+            wdbg = e ? atoi(e) : 0;
+        }
         if (src_dna)
             hipLaunchKernelGGL(level_scatter_wc_kernel<true>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
-                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot);
+                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, wdbg);
         else
             hipLaunchKernelGGL(level_scatter_wc_kernel<false>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
-                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot);
+                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, wdbg);
         return hipGetLastError();
     }
     switch (variant) {
@@ -734,21 +804,16 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 
         if (sorted_path) {
             reinterpret_cast<uint4 *>(H)[tid] = make_uint4(0, 0, 0, 0);
-            if (tid == 0)
-                H[BINS] = 0;
-            // Slots past the end of the leaf are not branched around: they carry an all-ones key,
-            // count in the extra bin BINS and so stage behind every real key.
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++)
-                if (tid + j * NT >= len)
-                    key[j] = ~(u64)0;
             __syncthreads();
             u32 rank[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
-                u32 b = i < len ? ((u32)(key[j] >> sshift) & smask) : (u32)BINS;
-                rank[j] = atomicAdd(&H[b], 1u);
+                rank[j] = 0;
+                // (slots past the end of the leaf take no part: an atomic on one shared dummy bin
+                // would serialise a third of the workgroup on a single LDS address)
+                if (i < len)
+                    rank[j] = atomicAdd(&H[(u32)(key[j] >> sshift) & smask], 1u);
             }
             __syncthreads();
             {   // exclusive scan of the bins, 4 consecutive bins per thread (16-byte LDS accesses)
@@ -780,8 +845,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
-                u32 b = i < len ? ((u32)(key[j] >> sshift) & smask) : (u32)BINS;
-                A[H[b] + rank[j]] = key[j];
+                if (i < len)
+                    A[H[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
             }
             __syncthreads();
             if (rem > sb && !(dbg & 1)) {
@@ -789,23 +854,25 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 #pragma unroll
                 for (int j = 0; j < ITEMS; j++) {
                     u32 i = tid + j * NT;
-                    u64 kv = A[i];
-                    key[j] = kv;
-                    u32 b = (u32)(kv >> sshift) & smask;
-                    u32 b0 = H[b];
-                    u32 b1 = i < len ? H[b + 1] : b0;
-                    u32 r = i < len ? b0 : i;
+                    if (i < len) {
+                        u64 kv = A[i];
+                        key[j] = kv;
+                        u32 b = (u32)(kv >> sshift) & smask;
+                        u32 b0 = H[b], b1 = H[b + 1];
+                        u32 r = b0;
 #pragma unroll 1
-                    for (u32 m = b0; m < b1; m++) {
-                        u64 o = A[m];
-                        r += (o < kv) || (o == kv && m < i);
+                        for (u32 m = b0; m < b1; m++) {
+                            u64 o = A[m];
+                            r += (o < kv) || (o == kv && m < i);
+                        }
+                        rank[j] = r;
                     }
-                    rank[j] = r;
                 }
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < ITEMS; j++)
-                    A[rank[j]] = key[j];
+                    if (tid + j * NT < len)
+                        A[rank[j]] = key[j];
                 __syncthreads();
             }
         }
@@ -916,7 +983,7 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, cons
         const char *e = getenv("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
         dbg = e ? atoi(e) : 0;
         const char *v = getenv("DNAGPU_LEAVES_VARIANT");
-        variant = v ? atoi(v) : 1;                       // 512 threads x 8 keys, 3 workgroups per CU
+        variant = v ? atoi(v) : 3;                       // 512 threads x 8 keys, 87 VGPRs, no scratch: 2 workgroups per CU
         const char *m = getenv("DNAGPU_LEAVES_GRIDMULT");
         mult = m ? atoi(m) : 1;
         if (mult < 1)
