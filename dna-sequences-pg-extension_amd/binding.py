@@ -80,6 +80,7 @@ def lib():
                                                  C.c_uint64, vp, vp, C.c_uint64, u64p, C.c_int]
     L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_count_keys.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.dnagpu_count_keys_in_range.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_hist_distinct.argtypes = [vp]
     L.dnagpu_hist_distinct.restype = C.c_uint64
     L.dnagpu_hist_total.argtypes = [vp]
@@ -323,6 +324,11 @@ class Context:
     def count_keys_device(self, dev_keys, n, k):
         h = C.c_void_p()
         _chk(lib().dnagpu_count_keys(self.h, dev_keys, n, k, C.byref(h)))
+        return Hist(self, h)
+
+    def count_keys_device_in_range(self, dev_keys, n, k, key_min, key_max):
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_keys_in_range(self.h, dev_keys, n, k, key_min, key_max, C.byref(h)))
         return Hist(self, h)
 
     def partition_kmers(self, dna, k, first, count, n_owners):

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 constexpr int WC_THREADS = 1024;
 constexpr int WC_ITEMS = 16;
 constexpr int WC_TILE = WC_THREADS * WC_ITEMS;          // 16384 staged keys
-constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 4 + 32 * 4;
+constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 5 + 32 * 4;
 
 template <bool SRC_DNA>
 __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
@@ -524,7 +524,8 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);     // R + 2 (counts, then offsets)
     u32 *offs = excl + ROW_STRIDE + 8;                                   // next output index per digit
     u32 *flsh = offs + ROW_STRIDE + 8;                                   // {delta, limit} per digit (uint2)
-    u32 *wtmp = flsh + 2 * (ROW_STRIDE + 8);                             // 16 + carry total
+    u32 *curs = flsh + 2 * (ROW_STRIDE + 8);                             // staging cursor per digit
+    u32 *wtmp = curs + ROW_STRIDE + 8;                                   // 16 + carry total
 
     if (blockIdx.x >= n_chunks)
         return;
@@ -578,31 +579,33 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
             excl[tid] = ccnt;
         if (tid == 0)
             excl[R] = 0;
-        if (SRC_DNA) {
-#pragma unroll
-            for (int j = 0; j < WC_ITEMS; j++)
-                key[j] = win16_key(w, j, mask);
-        }
         __syncthreads();
-        u32 pos[WC_ITEMS];
+        // count (non-returning LDS adds: no rank registers are kept; the dna root recomputes its
+        // windows from three packed words in both passes instead of holding 16 keys)
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
-            pos[j] = 0;
+            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[j];
             if (i < tn)                             // (no dummy digit: same-address LDS atomics serialise)
-                pos[j] = atomicAdd(&excl[(u32)(key[j] >> shift) & dmask], 1u);
+                atomicAdd(&excl[(u32)(kv >> shift) & dmask], 1u);
         }
         __syncthreads();
         {
             const u32 staged_total = block_scan_inplace<WC_THREADS>(excl, (int)R, wtmp);
             if (tid == 0)
-                excl[R] = staged_total;               // (visible after the barrier below)
+                excl[R] = staged_total;
         }
+        // digit d's cursor starts behind its carried keys; thread d re-stages those itself
+        if (tid < R)
+            curs[tid] = excl[tid] + ccnt;
+        __syncthreads();
+        // place: a returning add on the digit's cursor is the staged slot
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
+            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[j];
             if (i < tn)
-                stage[excl[(u32)(key[j] >> shift) & dmask] + pos[j]] = key[j];
+                stage[atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u)] = kv;
         }
         __syncthreads();                            // excl[R] (thread 0) and every stage write are visible
         u32 f = 0, m = 0, e0 = 0;

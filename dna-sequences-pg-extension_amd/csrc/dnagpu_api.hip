@@ -719,7 +719,7 @@ struct TreeResult {
 // `force_bits` bits on the root (force_bits > 0).  dna != null: root over the packed sequence
 // (keys land in buf0, allocated here); else root over keys_in (used as buf0).
 static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k,
-                    u64 *keys_in, int force_bits, TreeResult *res)
+                    u64 *keys_in, int force_bits, TreeResult *res, int fixed_bits = 0, u64 fixed_prefix = 0)
 {
     hipStream_t st = ctx->stream;
     u64 *buf0 = keys_in, *buf1 = nullptr;
@@ -727,7 +727,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     memset(&root, 0, sizeof root);
     root.start = 0;
     root.len = (u32)n;
-    root.meta = (u32)(2 * k);
+    root.meta = (u32)(2 * k - fixed_bits);      // bits every key is known to share are not split on
+    root.prefix = fixed_prefix;
     bool src_dna = false;
     if (dna) {
         RC_TRY(ps.alloc((size_t)n, &buf0));
@@ -813,7 +814,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 }
 
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
-                      dnagpu_hist **out)
+                      dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0)
 {
     if (n > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
@@ -829,7 +830,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     {
         PoolScope ps(ctx);
         TreeResult tr;
-        rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr);
+        rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         u64 *cursor = nullptr, *seg_off = nullptr;
         u32 *seg_cnt = nullptr;
         u64 *ok = nullptr, *oc = nullptr;
@@ -904,6 +905,26 @@ extern "C" int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n
         return DNAGPU_ERR_INVALID_K;
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, nullptr, 0, n, k, dev_keys, out);
+}
+
+extern "C" int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k,
+                                          uint64_t key_min, uint64_t key_max, dnagpu_hist **out)
+{
+    if (!ctx || !out || (n && !dev_keys) || key_min > key_max)
+        return DNAGPU_ERR_BAD_ARG;
+    if (k <= 0 || k > 32)
+        return DNAGPU_ERR_INVALID_K;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // number of leading bits (of the 2k key bits) that key_min and key_max share
+    const int nbits = 2 * k;
+    u64 diff = (key_min ^ key_max) & kmer_mask(k);
+    int free_bits = 0;
+    while (free_bits < nbits && (diff >> free_bits) != 0)
+        free_bits++;
+    const int fixed = nbits - free_bits;
+    const u64 prefix = free_bits >= 64 ? 0 : (key_min >> free_bits) << free_bits;
+    // a single possible key (fixed == 2k) still runs through the generic path: rem = 0 leaf
+    return count_core(ctx, nullptr, 0, n, k, dev_keys, out, fixed, prefix);
 }
 
 extern "C" uint64_t dnagpu_hist_distinct(const dnagpu_hist *h) { return h ? h->n_distinct : 0; }

@@ -18,6 +18,21 @@ import torch
 import torch.distributed as dist
 
 
+OWNER_BITS = 10     # dnagpu_partition_kmers partitions on the top min(2k, 10) key bits
+
+
+def owner_key_range(k, owner, world):
+    """[key_min, key_max] of the keys owner `owner` receives: digits d with (d * world) >> bits == owner."""
+    bits = min(2 * k, OWNER_BITS)
+    R = 1 << bits
+    d_lo = (owner * R + world - 1) // world
+    d_hi = ((owner + 1) * R + world - 1) // world       # exclusive
+    shift = 2 * k - bits
+    if d_hi <= d_lo:
+        return 0, 0
+    return d_lo << shift, (d_hi << shift) - 1
+
+
 def shard_ranges(n_bases, k, world):
     """Position ranges [lo, hi) of owned k-mer starts per rank, cut on 32-base (word) boundaries.
     Returns a list of (first_kmer, n_kmers, base_lo, base_hi) where [base_lo, base_hi) are the
@@ -72,9 +87,10 @@ class GpuEngine:
     def empty(self, n):
         return torch.empty(max(n, 1), dtype=torch.int64, device=self.device)[:n]
 
-    def count_keys(self, keys_t, k):
+    def count_keys(self, keys_t, k, key_min, key_max):
         torch.cuda.synchronize(self.device)
-        return self.ctx.count_keys_device(C.c_void_p(keys_t.data_ptr()), keys_t.numel(), k)
+        return self.ctx.count_keys_device_in_range(C.c_void_p(keys_t.data_ptr()), keys_t.numel(), k,
+                                                   key_min, key_max)
 
     def free_dna(self, dna):
         dna.free()
@@ -112,6 +128,7 @@ def count_sharded(engine, seed, n_bases, k, rank, world, dna=None):
         dna = engine.make_shard(seed, base_lo, base_hi)
     send, offsets = engine.partition(dna, k, n_mine, world)
     recv = exchange(send, offsets, world, engine)
-    hist = engine.count_keys(recv, k)
+    key_min, key_max = owner_key_range(k, rank, world)
+    hist = engine.count_keys(recv, k, key_min, key_max)
     engine.release()
     return hist, dna

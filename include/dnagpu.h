@@ -141,6 +141,10 @@ int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
 /* Same over an arbitrary array of n keys of k bases already in device memory.  dev_keys is used as
  * scratch and its contents are unspecified afterwards. */
 int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out);
+/* Same, when the caller knows that every key lies in [key_min, key_max] (an owner's key range after
+ * the multi-GPU exchange): the bits the two bounds share are not partitioned on again. */
+int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k,
+                               uint64_t key_min, uint64_t key_max, dnagpu_hist **out);
 
 uint64_t dnagpu_hist_distinct(const dnagpu_hist *h);   /* count(*) over groups                   */
 uint64_t dnagpu_hist_total(const dnagpu_hist *h);      /* sum(count)                              */

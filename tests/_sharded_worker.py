@@ -53,8 +53,10 @@ class OracleEngine:
     def empty(self, n):
         return torch.empty(n, dtype=torch.int64)
 
-    def count_keys(self, keys_t, k):
-        k_, c_ = orc.count_keys(keys_t.numpy().view(np.uint64))
+    def count_keys(self, keys_t, k, key_min, key_max):
+        keys = keys_t.numpy().view(np.uint64)
+        assert keys.size == 0 or (int(keys.min()) >= key_min and int(keys.max()) <= key_max)
+        k_, c_ = orc.count_keys(keys)
         return OracleHist(k_, c_)
 
     def free_dna(self, dna):

@@ -425,7 +425,14 @@ def test_partition_by_owner(ctx, n_owners):
             want = np.sort(sub[owner == o])
             assert hi - lo == len(want), f"owner {o}: {hi - lo} keys, oracle {len(want)}"
             if hi > lo:
-                h = ctx.count_keys_device(C.c_void_p(ptr + lo * 8), hi - lo, k)
+                import importlib
+                sh = importlib.import_module(load_package().__name__ + ".sharded")
+                kmin, kmax = sh.owner_key_range(k, o, n_owners)
+                assert int(want[0]) >= kmin and int(want[-1]) <= kmax
+                if o % 2:     # both entry points
+                    h = ctx.count_keys_device(C.c_void_p(ptr + lo * 8), hi - lo, k)
+                else:
+                    h = ctx.count_keys_device_in_range(C.c_void_p(ptr + lo * 8), hi - lo, k, kmin, kmax)
                 ok, oc = orc.count_keys(want)
                 check_hist(h, ok, oc, f"owner {o}/{n_owners} slice")
                 h.free()
