@@ -803,7 +803,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         const int sb = rem < SB ? rem : SB;
         const int sshift = rem - sb;
         const u32 smask = (1u << sb) - 1;
-        u64 hb[ITEMS];
+        u32 headbits = 0;                          // bit j: this thread's slot j starts a run
 
         if (sorted_path) {
             reinterpret_cast<uint4 *>(H)[tid] = make_uint4(0, 0, 0, 0);
@@ -899,9 +899,10 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
                 bool head = (i < len) & ((i == 0) | (A[i] != A[i ? i - 1 : 0]));
-                hb[j] = __ballot(head);
+                headbits |= head ? (1u << j) : 0u;
+                u64 hbj = __ballot(head);
                 if (lane == 0)
-                    rowcnt[j * WAVES + wave] = (u32)__popcll(hb[j]);
+                    rowcnt[j * WAVES + wave] = (u32)__popcll(hbj);
             }
             __syncthreads();
             if (wave == 0) {
@@ -931,9 +932,12 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         if (sorted_path) {
             const u64 below = ((u64)1 << lane) - 1;
 #pragma unroll
-            for (int j = 0; j < ITEMS; j++)
-                if ((hb[j] >> lane) & 1)
-                    H[rowcnt[j * WAVES + wave] + (u32)__popcll(hb[j] & below)] = tid + j * NT;
+            for (int j = 0; j < ITEMS; j++) {
+                const bool head = (headbits >> j) & 1;
+                const u64 hbj = __ballot(head);    // (recomputed: eight live ballots cost 16 SGPRs)
+                if (head)
+                    H[rowcnt[j * WAVES + wave] + (u32)__popcll(hbj & below)] = tid + j * NT;
+            }
             if (tid == 0)
                 H[D] = len;
             // (H as bin offsets is dead: every read of it happened before the barriers above)
