@@ -18,6 +18,8 @@ ERR_TOO_LARGE = 6
 ERR_NO_DEVICE = 7
 ERR_OOM = 8
 ERR_HIP = 9
+ERR_DNA_EMPTY = 11
+ERR_DNA_INVALID_CHAR = 12
 
 FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2
@@ -68,6 +70,9 @@ def lib():
     L.dnagpu_dna_wrap.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_dna_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_dna_download.argtypes = [vp, vp, u64p]
+    L.dnagpu_dna_pack.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(vp), u64p, C.c_char_p]
+    L.dnagpu_dna_unpack.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, C.c_int]
+    L.dnagpu_kmers_to_text.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_int]
     L.dnagpu_dna_length.argtypes = [vp]
     L.dnagpu_dna_length.restype = C.c_uint64
     L.dnagpu_dna_device_words.argtypes = [vp]
@@ -270,6 +275,35 @@ class Context:
         h = C.c_void_p()
         _chk(lib().dnagpu_dna_wrap(self.h, dev_ptr, n_words, n_bases, C.byref(h)))
         return Dna(self, h)
+
+    def pack(self, text):
+        """dna_in on the device: text (str/bytes of A/T/C/G) -> Dna"""
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        pos, ch = C.c_uint64(), C.create_string_buffer(1)
+        rc = lib().dnagpu_dna_pack(self.h, b, len(b), 0, C.byref(h), C.byref(pos), ch)
+        if rc == ERR_DNA_INVALID_CHAR:
+            e = DnaGpuError(rc)
+            e.message = f"{e.message}: {ch.raw.decode(errors='replace')}"
+            e.bad_pos = pos.value
+            e.args = (e.message,)
+            raise e
+        _chk(rc)
+        return Dna(self, h)
+
+    def unpack(self, dna, first=0, count=None):
+        if count is None:
+            count = dna.n_bases - first
+        buf = C.create_string_buffer(max(count, 1))
+        _chk(lib().dnagpu_dna_unpack(self.h, dna.h, first, count, buf, 0))
+        return buf.raw[:count].decode()
+
+    def kmers_to_text(self, keys, k):
+        a = np.ascontiguousarray(keys, dtype=np.uint64)
+        buf = C.create_string_buffer(max(a.size * (k + 1), 1))
+        _chk(lib().dnagpu_kmers_to_text(self.h, a.ctypes.data, a.size, k, buf, 0))
+        raw = buf.raw
+        return [raw[i * (k + 1): i * (k + 1) + k].decode() for i in range(a.size)]
 
     def synth(self, seed, n_bases, motif_len=0):
         h = C.c_void_p()

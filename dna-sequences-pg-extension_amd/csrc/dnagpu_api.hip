@@ -44,6 +44,8 @@ extern "C" const char *dnagpu_strerror(int status)
     case DNAGPU_ERR_OOM: return "out of memory";
     case DNAGPU_ERR_HIP: return "HIP runtime or kernel failure";
     case DNAGPU_ERR_INTERNAL: return "internal error";
+    case DNAGPU_ERR_DNA_EMPTY: return "DNA sequence cannot be empty";                         // dna.c:161
+    case DNAGPU_ERR_DNA_INVALID_CHAR: return "Invalid character in DNA sequence";              // dna.c:166 (+ ": %c")
     }
     return "unknown status";
 }
@@ -433,6 +435,97 @@ extern "C" int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint6
         HIP_TRY(hipMemcpyAsync(words, dna->words, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_pack(dnagpu_ctx *ctx, const char *text, uint64_t n_bases, int text_on_device,
+                               dnagpu_dna **out, uint64_t *bad_pos, char *bad_char)
+{
+    if (!ctx || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    if (n_bases == 0)
+        return DNAGPU_ERR_DNA_EMPTY;
+    if (!text)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    const unsigned char *dtext = reinterpret_cast<const unsigned char *>(text);
+    if (!text_on_device) {
+        unsigned char *stage = nullptr;
+        RC_TRY(ps.alloc((size_t)n_bases, &stage));
+        HIP_TRY(hipMemcpyAsync(stage, text, n_bases, hipMemcpyHostToDevice, ctx->stream));
+        dtext = stage;
+    }
+    u64 nw = words_for(n_bases);
+    u64 *words = nullptr, *bad = nullptr;
+    RC_TRY(ps.alloc((size_t)nw, &words));
+    RC_TRY(ps.alloc(1, &bad));
+    HIP_TRY(hipMemsetAsync(bad, 0xff, 8, ctx->stream));
+    HIP_TRY(launch_pack(dtext, n_bases, words, bad, ctx->stream));
+    u64 hbad = 0;
+    HIP_TRY(hipMemcpyAsync(&hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hbad != ~(u64)0) {
+        char c = 0;
+        HIP_TRY(hipMemcpy(&c, dtext + hbad, 1, hipMemcpyDeviceToHost));
+        if (bad_pos) *bad_pos = hbad;
+        if (bad_char) *bad_char = c;
+        set_err("Invalid character in DNA sequence: %c", c);
+        return DNAGPU_ERR_DNA_INVALID_CHAR;
+    }
+    dnagpu_dna *h = new (std::nothrow) dnagpu_dna{words, nw, n_bases, true};
+    if (!h)
+        return DNAGPU_ERR_OOM;
+    ps.release(words);
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t first, uint64_t count,
+                                 char *out_text, int out_on_device)
+{
+    if (!ctx || !dna || (count && !out_text))
+        return DNAGPU_ERR_BAD_ARG;
+    if (first > dna->n_bases || count > dna->n_bases - first)
+        return DNAGPU_ERR_BAD_ARG;
+    if (count == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    unsigned char *dt = reinterpret_cast<unsigned char *>(out_text);
+    if (!out_on_device)
+        RC_TRY(ps.alloc((size_t)count, &dt));
+    HIP_TRY(launch_unpack(dna->words, first, count, dt, ctx->stream));
+    if (!out_on_device)
+        HIP_TRY(hipMemcpyAsync(out_text, dt, count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k, char *out_text,
+                                    int on_device)
+{
+    if (!ctx || (n && (!keys || !out_text)))
+        return DNAGPU_ERR_BAD_ARG;
+    if (k <= 0 || k > 32)
+        return DNAGPU_ERR_INVALID_K;
+    if (n == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PoolScope ps(ctx);
+    const u64 *dk = keys;
+    unsigned char *dt = reinterpret_cast<unsigned char *>(out_text);
+    if (!on_device) {
+        u64 *tk = nullptr;
+        RC_TRY(ps.alloc((size_t)n, &tk));
+        RC_TRY(ps.alloc((size_t)n * (k + 1), &dt));
+        HIP_TRY(hipMemcpyAsync(tk, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        dk = tk;
+    }
+    HIP_TRY(launch_kmers_to_text(dk, n, k, dt, ctx->stream));
+    if (!on_device)
+        HIP_TRY(hipMemcpyAsync(out_text, dt, n * (u64)(k + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
 }
 

@@ -279,6 +279,134 @@ hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *r
 }
 
 // ------------------------------------------------------------------------------------------------
+// text <-> packed forms (the steps either side of the path: encode_dna dna.c:114-128 with the
+// validation of dna.c:159-171, decode_dna dna.c:135-152, decode_kmer dna.c:428-452)
+
+// 'A','T','C','G' -> 0,1,2,3 (dna.c:120-123); anything else -> 4
+__device__ __forceinline__ u32 base_code(u32 c)
+{
+    u32 t = (c >> 1) & 3;                        // A=0 C=1 T=2 G=3
+    u32 code = ((t & 1) << 1) | (t >> 1);        // A=0 T=1 C=2 G=3
+    u32 expect = (0x47544341u >> (8 * t)) & 0xff;   // "ACTG"[t]
+    return c == expect ? code : 4u;
+}
+
+// one thread per output word: 32 characters in, one packed word out; the position of the first
+// invalid character (what the reference reports) is kept with an atomic minimum
+__global__ __launch_bounds__(256) void pack_kernel(const unsigned char *__restrict__ text, u64 n_bases,
+                                                   u64 *__restrict__ words, unsigned long long *__restrict__ bad_pos)
+{
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 n_words = (n_bases + 31) / 32;
+    if (w >= n_words)
+        return;
+    const u64 base = w * 32;
+    u32 chunk[8];
+    if (base + 32 <= n_bases && ((reinterpret_cast<uintptr_t>(text) & 15) == 0)) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+        uint4 a = p[0], b = p[1];
+        chunk[0] = a.x; chunk[1] = a.y; chunk[2] = a.z; chunk[3] = a.w;
+        chunk[4] = b.x; chunk[5] = b.y; chunk[6] = b.z; chunk[7] = b.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            u32 v = 0;
+            for (int r = 0; r < 4; r++) {
+                u64 i = base + q * 4 + r;
+                v |= (i < n_bases ? (u32)text[i] : (u32)'A') << (8 * r);   // tail bits stay zero: 'A' = 00
+            }
+            chunk[q] = v;
+        }
+    }
+    u64 out = 0;
+    u32 first_bad = 32;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            u32 code = base_code((chunk[q] >> (8 * r)) & 0xff);
+            int j = q * 4 + r;
+            if (code > 3 && first_bad == 32)
+                first_bad = j;
+            out |= (u64)(code & 3) << (2 * j);
+        }
+    if (first_bad != 32)
+        atomicMin(bad_pos, (unsigned long long)(base + first_bad));
+    words[w] = out;
+}
+
+hipError_t launch_pack(const unsigned char *text, u64 n_bases, u64 *words, u64 *bad_pos, hipStream_t s)
+{
+    if (n_bases == 0)
+        return hipSuccess;
+    u64 n_words = (n_bases + 31) / 32;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, text, n_bases, words,
+                       reinterpret_cast<unsigned long long *>(bad_pos));
+    return hipGetLastError();
+}
+
+// bases [first, first+count) of the packed sequence -> count characters
+__global__ __launch_bounds__(256) void unpack_kernel(const u64 *__restrict__ words, u64 first, u64 count,
+                                                     unsigned char *__restrict__ text)
+{
+    u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= count)
+        return;
+    const u32 L = 0x47435441u;                   // codes 0..3 -> 'A','T','C','G'
+    unsigned char buf[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        u64 p = first + i0 + j;
+        u32 code = (u32)(words[p >> 5] >> ((p & 31) * 2)) & 3;
+        buf[j] = (unsigned char)((L >> (8 * code)) & 0xff);
+    }
+    if (i0 + 16 <= count && ((reinterpret_cast<uintptr_t>(text + i0) & 15) == 0)) {
+        uint4 v;                                 // one 16-byte store per lane: 1 KiB per wave-instruction
+        v.x = buf[0] | (buf[1] << 8) | (buf[2] << 16) | ((u32)buf[3] << 24);
+        v.y = buf[4] | (buf[5] << 8) | (buf[6] << 16) | ((u32)buf[7] << 24);
+        v.z = buf[8] | (buf[9] << 8) | (buf[10] << 16) | ((u32)buf[11] << 24);
+        v.w = buf[12] | (buf[13] << 8) | (buf[14] << 16) | ((u32)buf[15] << 24);
+        *reinterpret_cast<uint4 *>(text + i0) = v;
+    } else {
+        for (int j = 0; j < 16 && i0 + j < count; j++)
+            text[i0 + j] = buf[j];
+    }
+}
+
+hipError_t launch_unpack(const u64 *words, u64 first, u64 count, unsigned char *text, hipStream_t s)
+{
+    if (count == 0)
+        return hipSuccess;
+    u64 threads = (count + 15) / 16;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, words, first, count,
+                       text);
+    return hipGetLastError();
+}
+
+// n keys of k bases -> n records of k characters + NUL (stride k+1), kmer_out's text
+__global__ __launch_bounds__(256) void kmers_to_text_kernel(const u64 *__restrict__ keys, u64 n, int k,
+                                                            unsigned char *__restrict__ text)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const u32 L = 0x47435441u;
+    u64 key = keys[i];
+    unsigned char *o = text + i * (u64)(k + 1);
+    for (int j = 0; j < k; j++)
+        o[j] = (unsigned char)((L >> (8 * ((key >> (2 * j)) & 3))) & 0xff);
+    o[k] = 0;
+}
+
+hipError_t launch_kmers_to_text(const u64 *keys, u64 n, int k, unsigned char *text, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(kmers_to_text_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, k, text);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // exclusive scan of u32 arrays (tile offsets, node lists): reduce -> scan of block sums -> apply.
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;

@@ -27,6 +27,12 @@ hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_
 // result[0] += sum(count), result[1] += #(count == 1), result[2] += sum(pair_mix); zero it first
 hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *result3, hipStream_t s);
 
+// text <-> packed forms.  *bad_pos must hold ~0 before launch_pack; afterwards the position of the first
+// character that is not A/T/C/G (or still ~0)
+hipError_t launch_pack(const unsigned char *text, u64 n_bases, u64 *words, u64 *bad_pos, hipStream_t s);
+hipError_t launch_unpack(const u64 *words, u64 first, u64 count, unsigned char *text, hipStream_t s);
+hipError_t launch_kmers_to_text(const u64 *keys, u64 n, int k, unsigned char *text, hipStream_t s);
+
 // exclusive scan of n u32 values (in != out allowed, in == out allowed); *total receives the sum.
 // tmp must hold scan_tmp_words(n) u32 values.
 u64 scan_tmp_words(u64 n);

@@ -47,6 +47,8 @@ extern "C" {
 #define DNAGPU_ERR_OOM                  8   /* device or host allocation failed */
 #define DNAGPU_ERR_HIP                  9   /* a HIP call or kernel failed; see dnagpu_last_error() */
 #define DNAGPU_ERR_INTERNAL             10
+#define DNAGPU_ERR_DNA_EMPTY            11  /* dna.c:160-161 "DNA sequence cannot be empty" */
+#define DNAGPU_ERR_DNA_INVALID_CHAR     12  /* dna.c:165-166 "Invalid character in DNA sequence: %c" */
 
 const char *dnagpu_strerror(int status);
 /* detail text of the most recent failing call on the calling thread (HIP error string, etc.) */
@@ -88,6 +90,22 @@ int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t *words)
 uint64_t dnagpu_dna_length(const dnagpu_dna *dna);
 const uint64_t *dnagpu_dna_device_words(const dnagpu_dna *dna);
 void dnagpu_dna_free(dnagpu_ctx *ctx, dnagpu_dna *dna);
+
+/* ---- text <-> packed forms on the device (the steps either side of the path) ----------------
+ * dna_in's work, validate_dna_sequence + encode_dna (dna.c:159-171, 114-128): n_bases characters
+ * (host memory, or device memory when text_on_device != 0; no terminating NUL needed) become a
+ * device-resident dna.  An empty text is DNAGPU_ERR_DNA_EMPTY; a character other than A/T/C/G is
+ * DNAGPU_ERR_DNA_INVALID_CHAR with *bad_pos / *bad_char (either may be NULL) = the FIRST offending
+ * character, the one the reference's message names. */
+int dnagpu_dna_pack(dnagpu_ctx *ctx, const char *text, uint64_t n_bases, int text_on_device,
+                    dnagpu_dna **out, uint64_t *bad_pos, char *bad_char);
+/* decode_dna (dna.c:135-152): bases [first, first+count) as `count` characters (no NUL). */
+int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t first, uint64_t count,
+                      char *out_text, int out_on_device);
+/* decode_kmer / kmer_out (dna.c:428-452, 538-546) for n keys of k bases: n records of k characters
+ * followed by a NUL (record stride k+1).  keys and out_text both host, or both device. */
+int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k, char *out_text,
+                         int on_device);
 
 /* ---- generate_kmers(dna, k)  (dna.c:743-837, dna--1.0.sql:188-191) -------------------------- */
 

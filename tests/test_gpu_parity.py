@@ -53,6 +53,52 @@ def test_synth_matches_oracle(ctx, n):
     d.free()
 
 
+# ------------------------------------------------------------------ text <-> packed (dna_in / dna_out / kmer_out)
+
+@pytest.mark.parametrize("n", [1, 4, 31, 32, 33, 63, 64, 65, 1000, 100_003])
+def test_pack_unpack_matches_oracle(ctx, n):
+    words = orc.synth_words(555 + n, n)
+    text = orc.dna_decode(words, n)
+    d = ctx.pack(text)
+    assert d.n_bases == n
+    assert_same(d.download(), words, f"pack n={n}")
+    assert ctx.unpack(d) == text
+    if n > 40:
+        assert ctx.unpack(d, 7, 33) == text[7:40]
+    d.free()
+
+
+def test_pack_errors_are_the_references(ctx, pkg):
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.pack("")
+    assert ei.value.message == "DNA sequence cannot be empty"                      # dna.c:161
+    good = "ACGT" * 5000
+    for pos, ch in ((0, "N"), (17, "a"), (19_999, "X"), (4097, "U")):
+        bad = good[:pos] + ch + good[pos + 1:]
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            ctx.pack(bad)
+        assert ei.value.message == f"Invalid character in DNA sequence: {ch}"      # dna.c:166
+        assert ei.value.bad_pos == pos
+    # two bad characters: the first one is reported, as the reference's left-to-right scan does
+    bad = good[:100] + "z" + good[101:9000] + "y" + good[9001:]
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.pack(bad)
+    assert ei.value.message.endswith(": z") and ei.value.bad_pos == 100
+
+
+def test_kmers_to_text(ctx, ref_vectors):
+    v = ref_vectors["generate_kmers"][0]
+    d = ctx.pack(v["dna"])
+    assert ctx.kmers_to_text(ctx.generate_kmers(d, v["k"]), v["k"]) == v["rows"]     # test.sql:46-58
+    d.free()
+    rng = np.random.default_rng(5)
+    for k in (1, 7, 31, 32):
+        keys = rng.integers(0, 1 << 62, size=5000, dtype=np.uint64)
+        if k < 32:
+            keys &= np.uint64((1 << (2 * k)) - 1)
+        assert ctx.kmers_to_text(keys, k) == [orc.kmer_decode(int(x), k) for x in keys]
+
+
 # ------------------------------------------------------------------ generate_kmers
 
 def test_generate_kmers_reference_rows(ctx, ref_vectors):

@@ -55,3 +55,23 @@ with pkg.Context(0) as ctx:
         ctx.buffer_free(pb)
 for k_, v in out.items():
     print(k_, json.dumps(v))
+
+# text <-> packed (device-resident text in, so the rate is the kernel's, not PCIe's)
+with pkg.Context(0) as ctx:
+    import numpy as np
+    d = ctx.synth(0xD2A0001, n)
+    tbuf = ctx.buffer_alloc(n)
+    rc = pkg.lib().dnagpu_dna_unpack(ctx.h, d.h, 0, n, tbuf, 1)
+    best_u = best_p = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        pkg.lib().dnagpu_dna_unpack(ctx.h, d.h, 0, n, tbuf, 1)
+        best_u = min(best_u, time.perf_counter() - t0)
+    for _ in range(5):
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        rc = pkg.lib().dnagpu_dna_pack(ctx.h, C.cast(tbuf, C.c_char_p), n, 1, C.byref(h), None, None)
+        best_p = min(best_p, time.perf_counter() - t0)
+        pkg.lib().dnagpu_dna_free(ctx.h, h)
+    print("dna_pack", json.dumps({"ms": best_p * 1e3, "gbases_s": n / best_p / 1e9, "GBps": n * 1.25 / best_p / 1e9, "rc": rc}))
+    print("dna_unpack", json.dumps({"ms": best_u * 1e3, "gbases_s": n / best_u / 1e9, "GBps": n * 1.25 / best_u / 1e9}))
