@@ -35,7 +35,7 @@ PHASE_BYTES = {
     "scatter0": lambda n, d: 0.25 * n + 8.0 * n,    # packed input in, keys out
     "hist": lambda n, d: 8.0 * n,                   # keys in
     "scatter": lambda n, d: 16.0 * n,               # keys in, keys out
-    "leaves": lambda n, d: 8.0 * n + 16.0 * d,      # keys in, (key, count) groups out
+    "leaves": lambda n, d: 8.0 * n + 12.0 * d,      # keys in, (u64 key, u32 count) groups out
 }
 
 

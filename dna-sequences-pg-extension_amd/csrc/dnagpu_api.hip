@@ -97,7 +97,7 @@ struct dnagpu_dna {
 
 struct dnagpu_hist {
     u64 *keys;        // n_distinct groups, dense; stored leaf by leaf in completion order
-    u64 *counts;
+    u32 *counts;      // a count never exceeds the 2^32 - 1 rows of one call: 4 bytes in HBM, widened on download
     u64 n_distinct;
     u64 total;
     // segment directory: leaf l (leaves are in ascending key order) = seg_cnt[l] groups at seg_off[l]
@@ -926,7 +926,8 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         u64 *cursor = nullptr, *seg_off = nullptr;
         u32 *seg_cnt = nullptr;
-        u64 *ok = nullptr, *oc = nullptr;
+        u64 *ok = nullptr;
+        u32 *oc = nullptr;
         // a k-mer of k bases has at most 4^k distinct values
         u64 cap = n;
         if (k < 16)
@@ -1023,7 +1024,7 @@ extern "C" int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, u
 extern "C" uint64_t dnagpu_hist_distinct(const dnagpu_hist *h) { return h ? h->n_distinct : 0; }
 extern "C" uint64_t dnagpu_hist_total(const dnagpu_hist *h) { return h ? h->total : 0; }
 extern "C" const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h) { return h ? h->keys : nullptr; }
-extern "C" const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
+extern "C" const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
 
 // Ascending-key order through the segment directory: groups are gathered on the device into a
 // staging window, then copied to the host.

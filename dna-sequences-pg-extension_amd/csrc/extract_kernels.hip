@@ -238,7 +238,7 @@ hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_
 
 // sum(count), #(count == 1), wrapping sum of pair digests: three wave reductions + 3 atomics per block
 __global__ __launch_bounds__(256) void hist_summary_kernel(const u64 *__restrict__ keys,
-                                                           const u64 *__restrict__ counts, u64 n,
+                                                           const u32 *__restrict__ counts, u64 n,
                                                            u64 *__restrict__ result)
 {
     __shared__ u64 part[3][4];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void hist_summary_kernel(const u64 *__restrict
     }
 }
 
-hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *result3, hipStream_t s)
+hipError_t launch_hist_summary(const u64 *keys, const u32 *counts, u64 n, u64 *result3, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;

@@ -25,7 +25,7 @@ hipError_t launch_filter_write(const u64 *words, u64 n_words, u64 first, u64 cou
 hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s);
 hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_t *flags, hipStream_t s);
 // result[0] += sum(count), result[1] += #(count == 1), result[2] += sum(pair_mix); zero it first
-hipError_t launch_hist_summary(const u64 *keys, const u64 *counts, u64 n, u64 *result3, hipStream_t s);
+hipError_t launch_hist_summary(const u64 *keys, const u32 *counts, u64 n, u64 *result3, hipStream_t s);
 
 // text <-> packed forms.  *bad_pos must hold ~0 before launch_pack; afterwards the position of the first
 // character that is not A/T/C/G (or still ~0)
@@ -94,10 +94,10 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
-                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u64 *out_counts, hipStream_t s);
+                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
 // groups [first, first+count) of the ascending-key view -> dst arrays
 hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
-                                u64 first, u64 count, const u64 *keys, const u64 *counts, u64 *dst_keys,
+                                u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,
                                 u64 *dst_counts, hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array

@@ -150,7 +150,7 @@ int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k
 typedef struct dnagpu_hist dnagpu_hist;
 
 /* Groups rows [first, first+count) of generate_kmers(dna,k) by key.  The result lives in device
- * memory: n_distinct (key, count) pairs in two dense arrays.  Group order in those arrays is
+ * memory: n_distinct (key, count) pairs in two dense arrays (uint64 keys, uint32 counts).  Group order in those arrays is
  * unspecified, as it is in PostgreSQL (the arrays hold key-range segments in the order the GPU
  * finished them, keys ascending inside a segment); dnagpu_hist_download serves the groups in
  * ascending key order through the segment directory.  At most 2^32-1 rows per call. */
@@ -167,7 +167,9 @@ int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, 
 uint64_t dnagpu_hist_distinct(const dnagpu_hist *h);   /* count(*) over groups                   */
 uint64_t dnagpu_hist_total(const dnagpu_hist *h);      /* sum(count)                              */
 const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h);
-const uint64_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
+/* counts are 32-bit in device memory (one call covers at most 2^32 - 1 rows); dnagpu_hist_download
+ * widens them to the 64-bit count(*) of SQL */
+const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
 /* Copies groups [first, first+count) of the ASCENDING-KEY order to host arrays (either may be
  * NULL). */
 int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
