@@ -658,7 +658,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
             }
         }
         const u32 staged = excl[R];
-#pragma unroll 2
+#pragma unroll 4
         for (u32 i = tid; i < staged; i += WC_THREADS) {
             u64 kv = stage[i];
             uint2 dl = reinterpret_cast<const uint2 *>(flsh)[(u32)(kv >> shift) & dmask];
@@ -773,11 +773,13 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                                                           u32 *__restrict__ out_counts, int dbg)
 {
     constexpr int ITEMS = LEAF_CAP / NT;       // keys per thread
-    constexpr int BINS = NT * 4;               // counting-sort bins: one uint4 per thread
-    constexpr int SB = (NT == 1024) ? 12 : (NT == 512 ? 11 : 10);
+    constexpr int BINS = LEAF_CAP;             // counting-sort bins (mean occupancy 0.35-0.7)
+    constexpr int BPT = BINS / NT;             // consecutive bins per thread in the scan (4 or 8)
+    constexpr int SB = 12;
     constexpr int WAVES = NT / 64;
+    constexpr u32 BIG_BIN = 24;
     static_assert(ITEMS * WAVES == 64, "row/wave table must have 64 entries");
-    static_assert((1 << SB) == BINS, "bins");
+    static_assert((1 << SB) == BINS && BPT % 4 == 0, "bins");
 
     __shared__ __attribute__((aligned(16))) u64 A[LEAF_CAP];
     __shared__ __attribute__((aligned(16))) u32 H[LEAF_CAP + 8];   // bins -> offsets; later head positions
@@ -785,6 +787,10 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     __shared__ u32 wtmp[WAVES];
     __shared__ u32 sh_D;
     __shared__ u64 sh_obase;
+    __shared__ u32 big_n;                      // nonzero: some bin of this leaf has more than BIG_BIN members
+    __shared__ u32 big_cnt;
+    __shared__ u32 big_list[64];
+    __shared__ u32 uniform_bits[BINS / 32];   // bit b: bin b is big and all its members are equal
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 li = blockIdx.x;
@@ -817,7 +823,11 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         u32 headbits = 0;                          // bit j: this thread's slot j starts a run
 
         if (sorted_path) {
-            reinterpret_cast<uint4 *>(H)[tid] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < BPT / 4; q++)
+                reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q] = make_uint4(0, 0, 0, 0);
+            if (tid == 0)
+                big_n = 0;
             __syncthreads();
             u32 rank[ITEMS];
 #pragma unroll
@@ -830,9 +840,18 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     rank[j] = atomicAdd(&H[(u32)(key[j] >> sshift) & smask], 1u);
             }
             __syncthreads();
-            {   // exclusive scan of the bins, 4 consecutive bins per thread (16-byte LDS accesses)
-                uint4 v = reinterpret_cast<uint4 *>(H)[tid];
-                u32 sum = v.x + v.y + v.z + v.w, inc = sum;
+            {   // exclusive scan of the bins, BPT consecutive bins per thread (16-byte LDS accesses)
+                uint4 v[BPT / 4];
+                u32 sum = 0, cmax = 0;
+#pragma unroll
+                for (int q = 0; q < BPT / 4; q++) {
+                    v[q] = reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q];
+                    sum += v[q].x + v[q].y + v[q].z + v[q].w;
+                    cmax = max(max(cmax, max(v[q].x, v[q].y)), max(v[q].z, v[q].w));
+                }
+                if (cmax > BIG_BIN)                 // rare: some bin holds many copies of few keys
+                    big_n = 1;                      // (benign race: every writer stores 1)
+                u32 inc = sum;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     u32 t = __shfl_up(inc, off);
@@ -846,12 +865,16 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 const int wv = __builtin_amdgcn_readfirstlane(wave);
                 for (int w = 0; w < wv; w++)
                     base += wtmp[w];
-                uint4 o;
-                o.x = base;
-                o.y = base + v.x;
-                o.z = o.y + v.y;
-                o.w = o.z + v.z;
-                reinterpret_cast<uint4 *>(H)[tid] = o;
+#pragma unroll
+                for (int q = 0; q < BPT / 4; q++) {
+                    uint4 o;
+                    o.x = base;
+                    o.y = o.x + v[q].x;
+                    o.z = o.y + v[q].y;
+                    o.w = o.z + v[q].z;
+                    base = o.w + v[q].w;
+                    reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q] = o;
+                }
                 if (tid == 0)
                     H[BINS] = len;
             }
@@ -863,6 +886,37 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     A[H[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
             }
             __syncthreads();
+            const bool any_big = big_n != 0;           // (written before the scan's barriers)
+            u32 nbig = 0;
+            if (rem > sb && any_big) {
+                // A bin of hundreds of copies of ONE key (tandem repeats, satellites) would cost
+                // members^2 in the all-pairs ranking below; one wave checks "all members equal"
+                // in members/64 steps and such bins then keep their staged order.
+                for (u32 w = tid; w < BINS / 32; w += NT)
+                    uniform_bits[w] = 0;
+                if (tid == 0)
+                    big_cnt = 0;
+                __syncthreads();
+                for (u32 b = tid; b < (u32)BINS; b += NT)
+                    if (H[b + 1] - H[b] > BIG_BIN) {
+                        u32 slot = atomicAdd(&big_cnt, 1u);
+                        if (slot < 64)
+                            big_list[slot] = b;
+                    }
+                __syncthreads();
+                nbig = big_cnt < 64 ? big_cnt : 64;
+                for (u32 e = wave; e < nbig; e += WAVES) {
+                    const u32 b = big_list[e];
+                    const u32 s0 = H[b], s1 = H[b + 1];
+                    const u64 k0 = A[s0];
+                    bool same = true;
+                    for (u32 m = s0 + lane; m < s1; m += 64)
+                        same &= A[m] == k0;
+                    if (__all(same) && lane == 0)
+                        atomicOr(&uniform_bits[b >> 5], 1u << (b & 31));
+                }
+                __syncthreads();
+            }
             if (rem > sb && !(dbg & 1)) {
                 // exact rank inside each (small) bin: #smaller + #equal-before
                 // (walking a thread's eight slots in lock-step instead was measured: 9 % slower)
@@ -875,6 +929,10 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                         u32 b = (u32)(kv >> sshift) & smask;
                         u32 b0 = H[b], b1 = H[b + 1];
                         u32 r = b0;
+                        if (nbig > 0 && ((uniform_bits[b >> 5] >> (b & 31)) & 1)) {
+                            r = i;                 // all members equal: the staged order stands
+                            b1 = b0;
+                        }
 #pragma unroll 1
                         for (u32 m = b0; m < b1; m++) {
                             u64 o = A[m];
