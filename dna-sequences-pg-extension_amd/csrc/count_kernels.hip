@@ -515,11 +515,16 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 // tile.  Thread d owns digit d's carry in registers (R <= 1024 = workgroup size), so the LDS holds
 // one 16,384-key stage (128 KB) plus three small tables; every tile takes T - 7R new keys.
 constexpr int WC_THREADS = 1024;
-constexpr int WC_ITEMS = 16;
-constexpr int WC_TILE = WC_THREADS * WC_ITEMS;          // 16384 staged keys
-constexpr size_t WC_SMEM = (size_t)WC_TILE * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 5 + 32 * 4;
+constexpr int WC_ITEMS_KEYS = 16;                       // 16384 staged keys when the source is a key buffer
+constexpr int WC_ITEMS_DNA = 16;                        // same for the dna root, which recomputes its windows
+                                                        // in both passes (holding them: spills; a smaller
+                                                        // tile: measured 35 % slower, carry eats the stage)
+constexpr size_t wc_smem(int items)
+{
+    return (size_t)WC_THREADS * items * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 5 + 32 * 4;
+}
 
-template <bool SRC_DNA>
+template <bool SRC_DNA, int WC_ITEMS>
 __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
                                                                          const Chunk *__restrict__ chunks,
                                                                          u32 n_chunks,
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
                                                                          const u32 *__restrict__ hist,
                                                                          const u32 *__restrict__ tot, int dbg)
 {
+    constexpr int WC_TILE = WC_THREADS * WC_ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *stage = reinterpret_cast<u64 *>(smem);                          // WC_TILE keys
     u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);     // R + 2 (counts, then offsets)
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     u32 t0 = 0;
     u32 tn = ch.len < (u32)WC_TILE ? ch.len : (u32)WC_TILE;
     u32 per = (tn + WC_THREADS - 1) / WC_THREADS;         // dna root: consecutive windows per thread
-    u64 key[WC_ITEMS];
+    u64 key[SRC_DNA ? 1 : WC_ITEMS];
     Win16 w;
     if (SRC_DNA) {
         w = win16_load(words, n_words, first + origin + tid * per);
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = tid + j * WC_THREADS;
-            key[j] = NT_LOAD(&src[i < tn ? i : tn - 1]);
+            key[SRC_DNA ? 0 : j] = NT_LOAD(&src[i < tn ? i : tn - 1]);
         }
     }
 
@@ -591,12 +597,11 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
         if (tid == 0)
             excl[R] = 0;
         __syncthreads();
-        // count (non-returning LDS adds: no rank registers are kept; the dna root recomputes its
-        // windows from three packed words in both passes instead of holding 16 keys)
+        // count (non-returning LDS adds: no rank registers are kept)
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
-            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[j];
+            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
             if (i < tn)                             // (no dummy digit: same-address LDS atomics serialise)
                 atomicAdd(&excl[(u32)(kv >> shift) & dmask], 1u);
         }
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
-            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[j];
+            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
             if (i < tn)
                 stage[atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u)] = kv;
         }
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
 #pragma unroll
                 for (int j = 0; j < WC_ITEMS; j++) {
                     u32 i = tid + j * WC_THREADS;
-                    key[j] = NT_LOAD(&src[t0n + (i < tnn ? i : tnn - 1)]);
+                    key[SRC_DNA ? 0 : j] = NT_LOAD(&src[t0n + (i < tnn ? i : tnn - 1)]);
                 }
             }
         }
@@ -723,10 +728,10 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
     if (variant == 0) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_SMEM);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_SMEM);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_DNA>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_DNA));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
             attr_set = true;
         }
         static int wdbg = -1;
@@ -735,11 +740,13 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
             wdbg = e ? atoi(e) : 0;
         }
         if (src_dna)
-            hipLaunchKernelGGL(level_scatter_wc_kernel<true>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
-                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, wdbg);
+            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_DNA>), dim3(n_chunks), dim3(WC_THREADS),
+                               wc_smem(WC_ITEMS_DNA), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                               buf1, hist, tot, wdbg);
         else
-            hipLaunchKernelGGL(level_scatter_wc_kernel<false>, dim3(n_chunks), dim3(WC_THREADS), WC_SMEM, s, nodes,
-                               chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, wdbg);
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS>), dim3(n_chunks), dim3(WC_THREADS),
+                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                               buf1, hist, tot, wdbg);
         return hipGetLastError();
     }
     switch (variant) {
