@@ -513,7 +513,10 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 // tile only in whole 64-byte units of its destination: after staging, digit d flushes the keys up
 // to the last 64-byte boundary of its output stream and carries the rest (< 8 keys) into the next
 // tile.  Thread d owns digit d's carry in registers (R <= 1024 = workgroup size), so the LDS holds
-// one 16,384-key stage (128 KB) plus three small tables; every tile takes T - 7R new keys.
+// one 16,384-key stage (128 KB) plus small tables; a tile takes as many new keys as the stage has
+// room for beside the carried ones.  (Storing the carried keys straight from registers instead of
+// re-staging them frees that room but was measured 3.5x slower: 8-byte stores to 1024 different
+// lines per wave-instruction.)
 constexpr int WC_THREADS = 1024;
 constexpr int WC_ITEMS_KEYS = 16;                       // 16384 staged keys when the source is a key buffer
 constexpr int WC_ITEMS_DNA = 16;                        // same for the dna root, which recomputes its windows
