@@ -6,8 +6,8 @@
 
 A step = one full GROUP BY count over the whole synthetic sequence (extraction fused in), input
 already resident in HBM.  N=1: the single-GPU path (dnagpu_count_kmers) on all 3 Gbase.  N>1:
-the same 3 Gbase sharded by contiguous chunk over the ranks (strong scaling), one RCCL all-to-all
-of the keys by owner, local count (sharded.py).  Rank 0 prints ONE JSON line.
+the same 3 Gbase sharded by contiguous chunk over the ranks (strong scaling), one RCCL all-gather
+of the packed sequence, then every rank counts the key range it owns (sharded.py).  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
   roofline      the dominant kernel of the step: algorithmic bytes / its device time (HIP events on
@@ -101,10 +101,12 @@ def main():
         import importlib
         sh = importlib.import_module(pkg.__name__ + ".sharded")
         engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", local_rank))
-        state = {"dna": None}
+        state = {"chunk": None}
 
         def step():
-            h, state["dna"] = sh.count_sharded(engine, SEED, n_bases, k, rank, world, state["dna"])
+            # resident input = this rank's word chunk of the packed sequence; the step all-gathers
+            # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
+            h, state["chunk"] = sh.count_sharded(engine, SEED, n_bases, k, rank, world, state["chunk"])
             distinct[0] = h.distinct
             for name, ms in ctx.last_phase_times():
                 phases_acc.setdefault(name, []).append(ms)
@@ -155,7 +157,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"k={k} count over {n_bases} synthetic bases (splitmix64 seed {SEED:#x}), "
-                                   f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-to-all by key owner'}",
+                                   f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-gather of the packed sequence + owner-filtered count'}",
                        "n_bases": n_bases, "k": k, "distinct": distinct[0]},
             "roofline": roofline,
             "job_roofline": job,

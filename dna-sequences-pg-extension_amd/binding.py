@@ -85,6 +85,7 @@ def lib():
                                                  C.c_uint64, vp, vp, C.c_uint64, u64p, C.c_int]
     L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_count_keys.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.dnagpu_count_kmers_owned.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
     L.dnagpu_count_keys_in_range.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_hist_distinct.argtypes = [vp]
     L.dnagpu_hist_distinct.restype = C.c_uint64
@@ -353,6 +354,14 @@ class Context:
             count = max(total - first, 0)
         h = C.c_void_p()
         _chk(lib().dnagpu_count_kmers(self.h, dna.h, k, first, count, C.byref(h)))
+        return Hist(self, h)
+
+    def count_kmers_owned(self, dna, k, owner, n_owners, first=0, count=None):
+        total = kmer_count(dna.n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_kmers_owned(self.h, dna.h, k, first, count, owner, n_owners, C.byref(h)))
         return Hist(self, h)
 
     def count_keys_device(self, dev_keys, n, k):

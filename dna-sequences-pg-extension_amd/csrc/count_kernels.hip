@@ -218,6 +218,12 @@ __device__ __forceinline__ u64 win16_key(const Win16 &r, int j, u64 mask)
     return funnel(lo, hi, (rel & 31) * 2) & mask;
 }
 
+// Owner filter of a sharded count: at the dna root only the keys whose level-0 digit d satisfies
+// (d - lo) < span (unsigned) exist; span = ~0 keeps everything.
+struct DigitFilter {
+    u32 lo, span;
+};
+
 // ------------------------------------------------------------------------------------------------
 // level_hist: one workgroup per chunk -> hist[chunk][digit]
 template <bool SRC_DNA>
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                                                                 u64 first, u64 mask,
                                                                 const u64 *__restrict__ buf0,
                                                                 const u64 *__restrict__ buf1,
-                                                                u32 *__restrict__ hist)
+                                                                u32 *__restrict__ hist, DigitFilter flt)
 {
     __shared__ u32 h[ROW_STRIDE];
     if (blockIdx.x >= n_chunks)
@@ -245,9 +251,11 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
         for (u32 i0 = threadIdx.x * 16; i0 < ch.len; i0 += SC_THREADS * 16) {
             Win16 w = win16_load(words, n_words, first + origin + i0);
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                if (i0 + j < ch.len)
-                    atomicAdd(&h[(u32)(win16_key(w, j, mask) >> shift) & dmask], 1u);
+            for (int j = 0; j < 16; j++) {
+                u32 d = (u32)(win16_key(w, j, mask) >> shift) & dmask;
+                if (i0 + j < ch.len && d - flt.lo < flt.span)
+                    atomicAdd(&h[d], 1u);
+            }
         }
     } else {
         const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + origin;
@@ -262,16 +270,17 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
 
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, hipStream_t s)
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, hipStream_t s)
 {
+    const DigitFilter flt{flt_lo, flt_span};
     if (n_chunks == 0)
         return hipSuccess;
     if (src_dna)
         hipLaunchKernelGGL(level_hist_kernel<true>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt);
     else
         hipLaunchKernelGGL(level_hist_kernel<false>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt);
     return hipGetLastError();
 }
 
@@ -519,9 +528,6 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 // lines per wave-instruction.)
 constexpr int WC_THREADS = 1024;
 constexpr int WC_ITEMS_KEYS = 16;                       // 16384 staged keys when the source is a key buffer
-constexpr int WC_ITEMS_DNA = 16;                        // same for the dna root, which recomputes its windows
-                                                        // in both passes (holding them: spills; a smaller
-                                                        // tile: measured 35 % slower, carry eats the stage)
 constexpr size_t wc_smem(int items)
 {
     return (size_t)WC_THREADS * items * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 5 + 32 * 4;
@@ -692,6 +698,161 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The dna root's scatter: same aligned write combining, but a tile is filled from as many positions
+// of the packed sequence as it takes.  Without an owner filter that is "as many as the stage has
+// room for"; with one (sharded count: this GPU keeps 1/W of the key space and scans the whole
+// sequence) a tile sweeps about W x 16,384 positions, counting and then placing only its own keys.
+// Windows are recomputed in both sweeps (three packed words per 16 windows, a few VALU ops each):
+// far cheaper than a second LDS buffer.  If the keys found exceed the room (skewed data), the sweep
+// is halved and recounted; a sweep of `room` positions always fits.
+__global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
+    const Node *__restrict__ nodes, const Chunk *__restrict__ chunks, u32 n_chunks,
+    const u64 *__restrict__ words, u64 n_words, u64 first, u64 mask, u64 *__restrict__ buf0,
+    const u32 *__restrict__ hist, const u32 *__restrict__ tot, DigitFilter flt, int dbg)
+{
+    constexpr int WC_TILE = WC_THREADS * 16;
+    constexpr u32 BATCH = WC_THREADS * 16;        // positions per sweep step: 16 windows per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *stage = reinterpret_cast<u64 *>(smem);
+    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);
+    u32 *offs = excl + ROW_STRIDE + 8;
+    u32 *flsh = offs + ROW_STRIDE + 8;
+    u32 *curs = flsh + 2 * (ROW_STRIDE + 8);
+    u32 *wtmp = curs + ROW_STRIDE + 8;
+    u32 *sh_carry = wtmp + 16;
+
+    if (blockIdx.x >= n_chunks)
+        return;
+    const Chunk ch = chunks[blockIdx.x];
+    const Node nd = nodes[ch.node];
+    const int bits = (int)nd.split;
+    const int rem = (int)(nd.meta & 0xff);
+    if (bits == rem)
+        return;                                   // terminal split: nothing moves
+    const int shift = rem - bits;
+    const u32 R = 1u << bits, dmask = R - 1;
+    const u32 tid = threadIdx.x;
+    const u64 origin = (u64)nd.start + ch.off;
+    u64 *__restrict__ dst = buf0;
+    const u32 abase = (u32)((reinterpret_cast<uintptr_t>(dst) >> 3) & 7u);
+    // positions swept per key kept, about (the filter keeps span of R digits)
+    const u32 inv = flt.span >= R ? 1u : R / (flt.span ? flt.span : 1u);
+
+    if (tid < R)
+        offs[tid] = hist[(u64)blockIdx.x * ROW_STRIDE + tid] + tot[(u64)nd.chunk_base * ROW_STRIDE + tid];
+    if (tid == 0)
+        *sh_carry = 0;
+    u64 carry[7];
+    u32 ccnt = 0;
+#pragma unroll
+    for (int c = 0; c < 7; c++)
+        carry[c] = 0;
+    __syncthreads();
+
+    u32 t0 = 0;
+    while (t0 < ch.len) {
+        const u32 room = (u32)WC_TILE - *sh_carry;
+        const u32 remaining = ch.len - t0;
+        u32 P = room * inv;                       // positions of this tile
+        if (P > room)
+            P = P / BATCH * BATCH;
+        if (P > remaining)
+            P = remaining;
+        u32 staged_total;
+        for (;;) {
+            __syncthreads();                      // previous readers of excl are done
+            if (tid < R)
+                excl[tid] = ccnt;                 // counters start behind the carried keys
+            if (tid == 0) {
+                excl[R] = 0;
+                *sh_carry = 0;                    // (every thread has read `room`)
+            }
+            __syncthreads();
+            for (u32 b = 0; b < P; b += BATCH) {  // count sweep
+                const u32 bl = P - b < BATCH ? P - b : BATCH;
+                const u32 per = (bl + WC_THREADS - 1) / WC_THREADS;
+                const Win16 w = win16_load(words, n_words, first + origin + t0 + b + tid * per);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const u32 i = (u32)j < per ? tid * per + j : bl;
+                    const u32 d = (u32)(win16_key(w, j, mask) >> shift) & dmask;
+                    if (i < bl && d - flt.lo < flt.span)
+                        atomicAdd(&excl[d], 1u);
+                }
+            }
+            __syncthreads();
+            staged_total = block_scan_inplace<WC_THREADS>(excl, (int)R, wtmp);
+            if (staged_total <= (u32)WC_TILE || P <= room)
+                break;
+            P = P / 2;                            // more keys than room: sweep half as far
+            if (P < room)
+                P = room;
+            else if (P > BATCH)
+                P = P / BATCH * BATCH;
+        }
+        const bool last = t0 + P >= ch.len;
+        if (tid == 0)
+            excl[R] = staged_total;
+        if (tid < R)
+            curs[tid] = excl[tid] + ccnt;
+        __syncthreads();
+        for (u32 b = 0; b < P; b += BATCH) {      // place sweep: same windows, same filter
+            const u32 bl = P - b < BATCH ? P - b : BATCH;
+            const u32 per = (bl + WC_THREADS - 1) / WC_THREADS;
+            const Win16 w = win16_load(words, n_words, first + origin + t0 + b + tid * per);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const u32 i = (u32)j < per ? tid * per + j : bl;
+                const u64 kv = win16_key(w, j, mask);
+                const u32 d = (u32)(kv >> shift) & dmask;
+                if (i < bl && d - flt.lo < flt.span)
+                    stage[atomicAdd(&curs[d], 1u)] = kv;
+            }
+        }
+        __syncthreads();
+        u32 f = 0, m = 0, e0 = 0;
+        if (tid < R) {
+            e0 = excl[tid];
+            m = excl[tid + 1] - e0;                 // carried + new keys of this digit
+#pragma unroll
+            for (int c = 0; c < 7; c++)
+                if ((u32)c < ccnt)
+                    stage[e0 + c] = carry[c];
+            const u32 o = offs[tid];
+            const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
+            f = last ? m : (m >= tail ? m - tail : 0u);
+            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 + f);
+        }
+        {   // total carried into the next tile
+            u32 cn = m - f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                cn += __shfl_down(cn, off);
+            if ((tid & 63) == 0 && cn)
+                atomicAdd(sh_carry, cn);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (u32 i = tid; i < staged_total; i += WC_THREADS) {
+            u64 kv = stage[i];
+            uint2 dl = reinterpret_cast<const uint2 *>(flsh)[(u32)(kv >> shift) & dmask];
+            if (i < dl.y && !(dbg & 1))
+                NT_STORE(kv, &dst[(u64)(u32)(i + dl.x)]);
+        }
+        if (tid < R) {
+            ccnt = m - f;                           // <= 7
+#pragma unroll
+            for (int c = 0; c < 7; c++)
+                if ((u32)c < ccnt)
+                    carry[c] = stage[e0 + f + c];
+            offs[tid] += f;
+        }
+        __syncthreads();
+        t0 += P;
+    }
+}
+
 constexpr size_t SC_SMEM = (size_t)SC_TILE * 8 + (size_t)(ROW_STRIDE + 4) * 4 + (size_t)ROW_STRIDE * 4 + 16 * 4;
 
 template <int NT, int ITEMS, int MINW>
@@ -715,10 +876,11 @@ static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, con
 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
-                                const u32 *hist, const u32 *tot, hipStream_t s)
+                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, hipStream_t s)
 {
     if (n_chunks == 0)
         return hipSuccess;
+    const DigitFilter flt{flt_lo, flt_span};
     static int variant = -1;
     if (variant < 0) {
         const char *v = getenv("DNAGPU_SCATTER_VARIANT");
@@ -728,11 +890,13 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
         variant = v ? atoi(v) : 0;
     }
     const u64 mask = kmer_mask(k);
-    if (variant == 0) {
+    if (variant == 0 || (src_dna && flt_span != ~0u)) {     // the owner filter lives in the dna root kernel
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_DNA>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_DNA));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_dna_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(16));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
             attr_set = true;
@@ -742,9 +906,12 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
             const char *e = getenv("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results invalid when set
             wdbg = e ? atoi(e) : 0;
         }
-        if (src_dna)
-            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_DNA>), dim3(n_chunks), dim3(WC_THREADS),
-                               wc_smem(WC_ITEMS_DNA), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+        if (src_dna && flt_span != ~0u)           // sharded count: sweep the whole sequence, keep this owner's keys
+            hipLaunchKernelGGL(level_scatter_wc_dna_kernel, dim3(n_chunks), dim3(WC_THREADS), wc_smem(16), s, nodes,
+                               chunks, n_chunks, words, n_words, first, mask, buf0, hist, tot, flt, wdbg);
+        else if (src_dna)                         // unfiltered root: one position per staged key, next tile
+            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS>), dim3(n_chunks), dim3(WC_THREADS),
+                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
         else
             hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS>), dim3(n_chunks), dim3(WC_THREADS),

@@ -804,6 +804,7 @@ static const char *const LEVEL_PLAN_NAMES[] = {"level0_plan", "level1_plan", "le
 struct TreeResult {
     Node *nodes;      // final node list (leaves, or the children of a forced level)
     u32 n_nodes;
+    u64 n_keys;       // keys in the tree (== n unless an owner filter dropped some at the dna root)
     u64 *buf0;
     u64 *buf1;        // may be null if never needed
 };
@@ -812,7 +813,8 @@ struct TreeResult {
 // `force_bits` bits on the root (force_bits > 0).  dna != null: root over the packed sequence
 // (keys land in buf0, allocated here); else root over keys_in (used as buf0).
 static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k,
-                    u64 *keys_in, int force_bits, TreeResult *res, int fixed_bits = 0, u64 fixed_prefix = 0)
+                    u64 *keys_in, int force_bits, TreeResult *res, int fixed_bits = 0, u64 fixed_prefix = 0,
+                    bool single_level = true, u32 flt_lo = 0, u32 flt_span = ~0u)
 {
     hipStream_t st = ctx->stream;
     u64 *buf0 = keys_in, *buf1 = nullptr;
@@ -823,12 +825,13 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     root.meta = (u32)(2 * k - fixed_bits);      // bits every key is known to share are not split on
     root.prefix = fixed_prefix;
     bool src_dna = false;
+    u64 n_keys = n;
     if (dna) {
-        RC_TRY(ps.alloc((size_t)n, &buf0));
         if (n <= (u64)LEAF_CAP && force_bits == 0) {
+            RC_TRY(ps.alloc((size_t)n, &buf0));
             HIP_TRY(launch_extract(dna->words, dna->n_words, first, n, k, buf0, st));
         } else {
-            src_dna = true;
+            src_dna = true;                 // buffer 0 is allocated once level 0 knows how many keys it keeps
             root.meta |= NODE_BUF;          // children of the dna root go to buffer 0
         }
     }
@@ -851,7 +854,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
         RC_TRY(ps.alloc(1, &ctr));
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(LevelCounters), st));
-        HIP_TRY(launch_plan(cur, n_nodes, force_bits > 0 ? -force_bits : level, chunk_len, outc, nch, ctr, st));
+        HIP_TRY(launch_plan(cur, n_nodes, (force_bits > 0 && level == 0) ? -force_bits : level, chunk_len, outc, nch,
+                            ctr, st));
         HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
         HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
         LevelCounters hc;
@@ -874,16 +878,28 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, chunks, st));
         prof_mark(ctx, LEVEL_HIST_NAMES[li]);
         HIP_TRY(launch_level_hist(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
-                                  dna ? dna->n_words : 0, first, k, buf0, buf1, hist, st));
+                                  dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
+                                  src_dna ? flt_span : ~0u, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
         HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, chunk_len, hist, tot, st));
         HIP_TRY(launch_level_children(cur, n_nodes, tot, next, st));
+        if (src_dna) {
+            // the dna root's children say how many keys survive the owner filter
+            std::vector<Node> kids(hc.n_next);
+            HIP_TRY(hipMemcpyAsync(kids.data(), next, (size_t)hc.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_keys = 0;
+            for (const Node &c : kids)
+                n_keys += c.len;
+            RC_TRY(ps.alloc((size_t)std::max<u64>(n_keys, 1), &buf0));
+        }
         if (hc.n_scatter) {
             if (!src_dna && !buf1)
-                RC_TRY(ps.alloc((size_t)n, &buf1));
+                RC_TRY(ps.alloc((size_t)std::max<u64>(n_keys, 1), &buf1));
             prof_mark(ctx, LEVEL_SCATTER_NAMES[li]);
             HIP_TRY(launch_level_scatter(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
-                                         dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot, st));
+                                         dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot,
+                                         src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, st));
         }
         ps.free_now(outc);
         ps.free_now(nch);
@@ -896,18 +912,19 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         cur = next;
         n_nodes = hc.n_next;
         src_dna = false;
-        if (force_bits > 0)
+        if (force_bits > 0 && single_level)
             break;
     }
     res->nodes = cur;
     res->n_nodes = n_nodes;
+    res->n_keys = n_keys;
     res->buf0 = buf0;
     res->buf1 = buf1;
     return DNAGPU_OK;
 }
 
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
-                      dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0)
+                      dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1)
 {
     if (n > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
@@ -923,15 +940,25 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     {
         PoolScope ps(ctx);
         TreeResult tr;
-        rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
+        if (n_owners > 1) {
+            // sharded count: level 0 is forced onto the owner digits and keeps only this owner's keys
+            const int obits = std::min(2 * k, MAX_SPLIT_BITS);
+            const u32 R = 1u << obits;
+            const u32 d_lo = (u32)(((u64)owner * R + n_owners - 1) / n_owners);
+            const u32 d_hi = (u32)(((u64)(owner + 1) * R + n_owners - 1) / n_owners);
+            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo,
+                          d_hi > d_lo ? d_hi - d_lo : 0u);
+        } else {
+            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
+        }
         u64 *cursor = nullptr, *seg_off = nullptr;
         u32 *seg_cnt = nullptr;
         u64 *ok = nullptr;
         u32 *oc = nullptr;
         // a k-mer of k bases has at most 4^k distinct values
-        u64 cap = n;
+        u64 cap = rc == DNAGPU_OK ? std::max<u64>(tr.n_keys, 1) : 1;
         if (k < 16)
-            cap = std::min<u64>(n, (u64)1 << (2 * k));
+            cap = std::min<u64>(cap, (u64)1 << (2 * k));
         if (rc == DNAGPU_OK) rc = ps.alloc(1, &cursor);
         if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &seg_off);
         if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &seg_cnt);
@@ -989,6 +1016,26 @@ extern "C" int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, dna, first, count, k, nullptr, out);
+}
+
+extern "C" int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                                        uint64_t count, int owner, int n_owners, dnagpu_hist **out)
+{
+    if (!ctx || !dna || !out || n_owners < 1 || owner < 0 || owner >= n_owners)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, owner, n_owners);
+    if (rc == DNAGPU_OK && n_owners > 1) {
+        // rows owned = sum(count) over the groups: computed on the device
+        u64 total = 0;
+        rc = dnagpu_hist_summary(ctx, *out, &total, nullptr, nullptr);
+        if (rc == DNAGPU_OK)
+            (*out)->total = total;
+        else
+            dnagpu_hist_free(ctx, *out);
+    }
+    return rc;
 }
 
 extern "C" int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out)

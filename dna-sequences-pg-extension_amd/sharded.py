@@ -1,15 +1,24 @@
-"""Multi-GPU k-mer count: one process per GPU, contiguous sequence shards, one key exchange.
+"""Multi-GPU k-mer count: one process per GPU, the sequence sharded by contiguous chunk.
 
-The sequence shards by contiguous chunk: rank r owns the k-mers that START in its
-range of positions, and reads k-1 halo bases past its range so none is lost or counted twice.  The
-count itself needs one real exchange: equal k-mers found on different ranks must meet.  Keys are
-partitioned by owner = contiguous ranges of their top bits (dnagpu_partition_kmers), exchanged with
-one all-to-all (RCCL over xGMI when the backend is "nccl"), and counted where they land
-(dnagpu_count_keys).  The global result is the concatenation of the ranks' results in rank order,
-keys ascending.
+Counting needs one real exchange: equal k-mers found in different chunks must meet.  Two ways, both
+with the same ownership rule (owner o of W owns the keys whose top-10-bit digit d satisfies
+(d * W) >> 10 == o: contiguous, ascending key ranges, so the concatenation of the ranks' results in
+rank order is the global result in ascending key order):
 
-The engine is injected so that the host logic (shard arithmetic, split sizes, the collective) is
-covered by world_size-2 gloo tests on CPU with the oracle standing in for the GPU; the product
+``count_sharded`` (default)   all-gather the PACKED SEQUENCE (2 bits per base, RCCL over xGMI), then
+    every rank scans all of it and keeps only the keys it owns (dnagpu_count_kmers_owned).  The
+    exchange is 64x smaller than moving keys -- at 3 Gbase each rank receives 0.75 GB instead of
+    sending 21/W GB of keys -- at the price of every rank extracting every window, which is cheap
+    (a few VALU ops per window).  With two ranks joined by one xGMI link the key exchange would take
+    longer than the whole single-GPU count; this does not.
+
+``count_sharded_exchange_keys``   rank r extracts only its own chunk (+ k-1 halo bases), partitions
+    the keys by owner (dnagpu_partition_kmers), exchanges them with one all-to-all and counts what
+    it receives (dnagpu_count_keys_in_range).  Kept as the alternative for many GPUs / very long
+    sequences, where scanning everything on every rank stops being free.
+
+The engine is injected so that the host logic (chunk arithmetic, collectives, split sizes) is
+covered by world_size-2/3 gloo tests on CPU with the oracle standing in for the GPU; the product
 engine is GpuEngine below and nothing else.
 """
 import ctypes as C
@@ -17,12 +26,11 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-
-OWNER_BITS = 10     # dnagpu_partition_kmers partitions on the top min(2k, 10) key bits
+OWNER_BITS = 10     # the level-0 digit: top min(2k, 10) key bits
 
 
 def owner_key_range(k, owner, world):
-    """[key_min, key_max] of the keys owner `owner` receives: digits d with (d * world) >> bits == owner."""
+    """[key_min, key_max] of the keys owner `owner` holds: digits d with (d * world) >> bits == owner."""
     bits = min(2 * k, OWNER_BITS)
     R = 1 << bits
     d_lo = (owner * R + world - 1) // world
@@ -33,10 +41,23 @@ def owner_key_range(k, owner, world):
     return d_lo << shift, (d_hi << shift) - 1
 
 
+def word_chunks(n_bases, world):
+    """Equal word chunks of the packed sequence: rank r is resident with words [r*per, (r+1)*per).
+    Returns (per_words, [(word_lo, n_bases_in_chunk)] per rank)."""
+    n_words = (n_bases + 31) // 32
+    per = (n_words + world - 1) // world
+    out = []
+    for r in range(world):
+        lo = min(r * per, n_words)
+        hi = min((r + 1) * per, n_words)
+        out.append((lo, max(min(hi * 32, n_bases) - lo * 32, 0)))
+    return per, out
+
+
 def shard_ranges(n_bases, k, world):
-    """Position ranges [lo, hi) of owned k-mer starts per rank, cut on 32-base (word) boundaries.
-    Returns a list of (first_kmer, n_kmers, base_lo, base_hi) where [base_lo, base_hi) are the
-    bases the rank must hold (its range plus the k-1 base halo)."""
+    """Position ranges of owned k-mer starts per rank for the key-exchange variant, cut on 32-base
+    (word) boundaries.  Returns (first_kmer, n_kmers, base_lo, base_hi) per rank where
+    [base_lo, base_hi) are the bases the rank holds (its range plus the k-1 base halo)."""
     n_kmers = n_bases - k + 1 if n_bases >= k else 0
     words = (n_kmers + 31) // 32
     per = (words + world - 1) // world
@@ -65,9 +86,34 @@ class GpuEngine:
         self.pkg, self.ctx, self.device = pkg, ctx, device
         self._held = []
 
+    # ---- resident input
+    def make_chunk(self, seed, word_lo, n_bases_chunk):
+        """words [word_lo, ...) of the global synthetic stream (word w = splitmix64(seed + w))"""
+        return self.ctx.synth(seed + word_lo, n_bases_chunk)
+
+    def chunk_tensor(self, dna, per_words):
+        """the chunk as an int64 tensor of per_words words (zero padded) for the all-gather"""
+        t = torch.zeros(per_words, dtype=torch.int64, device=self.device)
+        nw = (dna.n_bases + 31) // 32
+        if nw:
+            src = torch.as_tensor(_DevArray(dna.device_words, nw), device=self.device)
+            self.ctx.synchronize()
+            t[:nw].copy_(src)
+        return t
+
+    def empty(self, n):
+        return torch.empty(max(n, 1), dtype=torch.int64, device=self.device)[:n]
+
+    def count_owned(self, words_t, n_bases, k, rank, world):
+        torch.cuda.synchronize(self.device)
+        dna = self.ctx.wrap(C.c_void_p(words_t.data_ptr()), words_t.numel(), n_bases)
+        try:
+            return self.ctx.count_kmers_owned(dna, k, rank, world)
+        finally:
+            dna.free()
+
+    # ---- key-exchange variant
     def make_shard(self, seed, base_lo, base_hi):
-        # word w of the global synthetic stream is splitmix64(seed + w): a shard is the same
-        # generator started at its first word
         assert base_lo % 32 == 0
         return self.ctx.synth(seed + base_lo // 32, base_hi - base_lo)
 
@@ -84,9 +130,6 @@ class GpuEngine:
             self.ctx.buffer_free(p)
         self._held = []
 
-    def empty(self, n):
-        return torch.empty(max(n, 1), dtype=torch.int64, device=self.device)[:n]
-
     def count_keys(self, keys_t, k, key_min, key_max):
         torch.cuda.synchronize(self.device)
         return self.ctx.count_keys_device_in_range(C.c_void_p(keys_t.data_ptr()), keys_t.numel(), k,
@@ -96,14 +139,40 @@ class GpuEngine:
         dna.free()
 
 
+def gather_sequence(chunk_t, world, engine):
+    """All-gather of the packed chunks -> the whole packed sequence on every rank."""
+    if world == 1:
+        return chunk_t
+    via_host = dist.get_backend() == "gloo" and chunk_t.is_cuda     # gloo has no device all-gather
+    if via_host:
+        full_h = torch.empty(world * chunk_t.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(full_h, chunk_t.cpu())
+        full = engine.empty(full_h.numel())
+        full.copy_(full_h)
+        return full
+    full = engine.empty(world * chunk_t.numel())
+    dist.all_gather_into_tensor(full, chunk_t)
+    return full
+
+
+def count_sharded(engine, seed, n_bases, k, rank, world, chunk=None):
+    """One full sharded count (all-gather of the packed sequence + owner-filtered count).
+    Returns (hist, chunk): this rank's part of the global histogram and its resident chunk."""
+    per, chunks = word_chunks(n_bases, world)
+    if chunk is None:
+        chunk = engine.make_chunk(seed, *chunks[rank])
+    chunk_t = engine.chunk_tensor(chunk, per)
+    full = gather_sequence(chunk_t, world, engine)
+    hist = engine.count_owned(full, n_bases, k, rank, world)
+    return hist, chunk
+
+
 def exchange(send, offsets, world, engine):
     """All-to-all of the owner groups.  send: int64 tensor grouped by owner; offsets[o]..offsets[o+1]
     is owner o's group.  Returns the keys this rank owns (unordered)."""
     in_splits = [offsets[o + 1] - offsets[o] for o in range(world)]
     if world == 1:
         return send
-    # gloo has no device all-to-all: stage through the host (test rigs only; RCCL moves device
-    # buffers directly over xGMI)
     via_host = dist.get_backend() == "gloo" and send.is_cuda
     sizes = torch.tensor(in_splits, dtype=torch.int64, device="cpu" if via_host else send.device)
     recv_sizes = torch.empty_like(sizes)
@@ -120,9 +189,8 @@ def exchange(send, offsets, world, engine):
     return recv
 
 
-def count_sharded(engine, seed, n_bases, k, rank, world, dna=None):
-    """One full sharded count.  Returns (hist, dna) where hist is this rank's part of the global
-    histogram (an engine object with .distinct/.total) and dna the shard (kept resident)."""
+def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None):
+    """The key-exchange variant.  Returns (hist, dna) like count_sharded."""
     first, n_mine, base_lo, base_hi = shard_ranges(n_bases, k, world)[rank]
     if dna is None:
         dna = engine.make_shard(seed, base_lo, base_hi)

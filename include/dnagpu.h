@@ -188,6 +188,12 @@ void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h);
  * by owner, owner_offsets[0..n_owners] the group boundaries.  Free with dnagpu_buffer_free.
  * Step 2 (caller): exchange the groups.  Step 3: dnagpu_count_keys on what was received; the
  * concatenation of the owners' downloads in owner order is the global result, keys ascending. */
+/* Alternative without moving keys (the default of sharded.py): every rank holds the whole packed
+ * sequence (an all-gather of 2 bits per base instead of an all-to-all of 64 bits per k-mer), scans
+ * all of it and keeps only the keys it owns (same owner rule as above).  The histogram covers
+ * exactly this owner's key range; dnagpu_hist_total() is the number of rows it owns. */
+int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                             uint64_t count, int owner, int n_owners, dnagpu_hist **out);
 int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                            uint64_t first, uint64_t count, int n_owners,
                            uint64_t **dev_keys, uint64_t *owner_offsets);

@@ -34,6 +34,26 @@ class OracleHist:
 class OracleEngine:
     """Same interface as sharded.GpuEngine, computed by the oracle (tests only)."""
 
+    # ---- all-gather variant
+    def make_chunk(self, seed, word_lo, n_bases_chunk):
+        return (orc.synth_words(seed + word_lo, n_bases_chunk), n_bases_chunk)
+
+    def chunk_tensor(self, chunk, per_words):
+        words, n = chunk
+        t = torch.zeros(per_words, dtype=torch.int64)
+        t[:len(words)] = torch.from_numpy(words.view(np.int64).copy())
+        return t
+
+    def count_owned(self, words_t, n_bases, k, rank, world):
+        words = words_t.numpy().view(np.uint64)[: (n_bases + 31) // 32]
+        keys = orc.generate_kmers(words, n_bases, k, faithful=False)
+        bits = min(2 * k, 10)
+        owner = ((keys >> np.uint64(2 * k - bits)) * np.uint64(world)) >> np.uint64(bits)
+        k_, c_ = orc.count_keys(keys[owner == rank])
+        return OracleHist(k_, c_)
+
+    # ---- key-exchange variant
+
     def make_shard(self, seed, base_lo, base_hi):
         n = base_hi - base_lo
         return (orc.synth_words(seed + base_lo // 32, n), n)
@@ -65,6 +85,7 @@ class OracleEngine:
 
 def main():
     engine_name, n_bases, k, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "gather"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_package()
@@ -76,7 +97,10 @@ def main():
         engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", 0))
     else:
         engine = OracleEngine()
-    hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world)
+    if mode == "gather":
+        hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world)
+    else:
+        hist, dna = sh.count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world)
     keys, counts = hist.download()
     parts = [None] * world
     dist.all_gather_object(parts, (np.asarray(keys), np.asarray(counts)))
@@ -88,11 +112,12 @@ def main():
         res = {"ok": bool(np.array_equal(gk, ok) and np.array_equal(gc, oc)),
                "distinct": int(len(gk)), "oracle_distinct": int(len(ok)),
                "sorted": bool(np.all(gk[1:] > gk[:-1])) if len(gk) > 1 else True,
-               "per_rank": [int(len(p[0])) for p in parts]}
+               "per_rank": [int(len(p[0])) for p in parts], "total": int(hist.total)}
         with open(out_path, "w") as f:
             json.dump(res, f)
     hist.free()
-    engine.free_dna(dna)
+    if engine_name == "gpu":
+        dna.free()
     dist.barrier()
     dist.destroy_process_group()
     if ctx is not None:

@@ -486,6 +486,31 @@ def test_partition_by_owner(ctx, n_owners):
     d.free()
 
 
+@pytest.mark.parametrize("n_owners", [2, 3, 8])
+def test_count_kmers_owned(ctx, n_owners):
+    # every owner scans the whole sequence and keeps its key range; the union is the full histogram
+    for n, k, motif in ((500_000, 31, 0), (300_000, 21, 1000), (120_000, 8, 0), (40_000, 3, 0)):
+        d = ctx.synth(77, n, motif_len=motif)
+        words = d.download()
+        keys = orc.generate_kmers(words, n, k, faithful=False)
+        bits = min(2 * k, 10)
+        owner = ((keys >> np.uint64(2 * k - bits)) * np.uint64(n_owners)) >> np.uint64(bits)
+        all_k, all_c = [], []
+        for o in range(n_owners):
+            h = ctx.count_kmers_owned(d, k, o, n_owners)
+            ok, oc = orc.count_keys(keys[owner == o])
+            check_hist(h, ok, oc, f"owned n={n} k={k} owner {o}/{n_owners}")
+            assert h.total == int((owner == o).sum())
+            gk, gc = h.download()
+            all_k.append(gk)
+            all_c.append(gc)
+            h.free()
+        fk, fc = orc.count_keys(keys)
+        assert_same(np.concatenate(all_k), fk, "owners concatenated = global keys")
+        assert_same(np.concatenate(all_c), fc, "owners concatenated = global counts")
+        d.free()
+
+
 # ------------------------------------------------------------------ BASELINE.json sizes (properties)
 
 def test_config2_k21_100M_against_oracle_summary(ctx):

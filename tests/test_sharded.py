@@ -11,14 +11,14 @@ import pytest
 from __graft_entry__ import ROOT, load_package
 
 
-def run_world(engine, world, n_bases, k, tmp_path, port):
-    out = tmp_path / f"res_{engine}_{world}_{n_bases}_{k}.json"
+def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather"):
+    out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}.json"
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"),
-                                       engine, str(n_bases), str(k), str(out)], env=env))
+                                       engine, str(n_bases), str(k), str(out), mode], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     return json.loads(out.read_text())
@@ -39,14 +39,31 @@ def test_shard_ranges_cover_exactly_once():
             pos += cnt
 
 
+def test_word_chunks_cover_the_sequence():
+    pkg = load_package()
+    sh = importlib.import_module(pkg.__name__ + ".sharded")
+    for n, w in [(1000, 2), (1000, 8), (64, 3), (31, 4), (3_000_000_000, 8), (33, 5)]:
+        per, chunks = sh.word_chunks(n, w)
+        assert sum(c[1] for c in chunks) == n
+        pos = 0
+        for lo, nb in chunks:
+            assert nb == 0 or lo * 32 == pos
+            assert nb <= per * 32
+            pos += nb
+
+
+@pytest.mark.parametrize("mode", ["gather", "keys"])
 @pytest.mark.parametrize("world,n_bases,k", [(2, 200_000, 31), (3, 100_001, 21), (2, 5000, 8)])
-def test_sharded_count_gloo_oracle_engine(tmp_path, world, n_bases, k):
-    res = run_world("oracle", world, n_bases, k, tmp_path, 29511 + world)
+def test_sharded_count_gloo_oracle_engine(tmp_path, world, n_bases, k, mode):
+    res = run_world("oracle", world, n_bases, k, tmp_path, 29511 + world + (10 if mode == "keys" else 0), mode)
     assert res["ok"] and res["sorted"], res
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 21)])
-def test_sharded_count_gloo_gpu_engine(tmp_path, world, n_bases, k):
-    res = run_world("gpu", world, n_bases, k, tmp_path, 29521 + world)
+@pytest.mark.parametrize("mode", ["gather", "keys"])
+@pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 21), (2, 70_000, 4)])
+def test_sharded_count_gloo_gpu_engine(tmp_path, world, n_bases, k, mode):
+    if mode == "keys" and k < 6:
+        pytest.skip("the key-exchange variant needs 2k > 10 bits")
+    res = run_world("gpu", world, n_bases, k, tmp_path, 29531 + world + (10 if mode == "keys" else 0), mode)
     assert res["ok"] and res["sorted"], res
