@@ -841,7 +841,14 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
     u32 n_nodes = 1;
 
-    u32 chunk_len = (u32)std::max<u64>(4 * (u64)scatter_tile_keys(), (n + 4095) / 4096);
+    static u64 chunk_target = 0;                 // chunks per level (work units of the hist/scatter kernels)
+    if (chunk_target == 0) {
+        const char *e = getenv("DNAGPU_CHUNKS");
+        chunk_target = e ? (u64)atoll(e) : 4096;
+        if (chunk_target < 256)
+            chunk_target = 256;
+    }
+    u32 chunk_len = (u32)std::max<u64>(4 * (u64)scatter_tile_keys(), (n + chunk_target - 1) / chunk_target);
     chunk_len = (chunk_len + scatter_tile_keys() - 1) / scatter_tile_keys() * scatter_tile_keys();
 
     for (int level = 0;; level++) {
