@@ -72,8 +72,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # nccl (= RCCL over xGMI) is the product path.  BENCH_BACKEND=gloo with BENCH_ONE_GPU=1 is a
+        # rehearsal rig only: all ranks share GPU 0 and collectives are staged through the host.
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if os.environ.get("BENCH_ONE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ctx = pkg.Context(local_rank)
@@ -122,10 +130,11 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        dsum = torch.tensor([distinct[0]], dtype=torch.int64, device="cuda")
+        dsum = torch.tensor([distinct[0]], dtype=torch.int64, device=red_dev)
         dist.all_reduce(dsum)
         distinct[0] = int(dsum.item())
 
