@@ -18,6 +18,7 @@
 //   which is how heavy hitters and small k terminate.
 //
 // Output: groups in ascending key order; bit-exact against the oracle's sorted hash-aggregate.
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -35,6 +36,36 @@
 
 namespace dnagpu {
 
+// Diagnostic build only (make STAMPS=1): thread 0 of every workgroup accumulates shader-clock cycles
+// per phase of the scatter / leaves kernels; DNAGPU_STAMPS=1 prints the totals after each launch.
+#ifdef DNAGPU_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_last = __builtin_readcyclecounter();
+#define STAMP(k) do { if (threadIdx.x == 0) { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[k] += st_now - st_last; st_last = st_now; } } while (0)
+#define STAMP_FLUSH(base) do { if (threadIdx.x == 0) { for (int st_i = 0; st_i < 12; st_i++) atomicAdd(&g_stamps[(base) + st_i], st_acc[st_i]); } } while (0)
+static void stamps_report(const char *what, int base, hipStream_t s)
+{
+    const char *e = getenv("DNAGPU_STAMPS");
+    if (!e || !atoi(e))
+        return;
+    unsigned long long h[32], z[32] = {0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+    unsigned long long tot = 0;
+    for (int i = 0; i < 12; i++)
+        tot += h[base + i];
+    fprintf(stderr, "[stamps] %s:", what);
+    for (int i = 0; i < 12; i++)
+        fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * h[base + i] / tot : 0.0);
+    fprintf(stderr, " total=%.3e cycles\n", (double)tot);
+}
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH(base)
+#endif
+
 constexpr int SC_THREADS = 1024;              // level_hist workgroup
 constexpr int SC_TILE = 8192;                 // keys staged in LDS per scatter tile
 
@@ -46,6 +77,27 @@ __device__ __forceinline__ int ceil_log2_u32(u32 x)
     return x <= 1 ? 0 : 32 - __clz(x - 1);
 }
 
+// Inclusive scan over the 64 lanes of a wave with DPP adds (row shifts inside rows of 16, then two row
+// broadcasts): six VALU instructions.  The __shfl_up form is six ds_bpermute round trips through
+// the LDS crossbar -- measured with cycle stamps, the 1024-element scan of a scatter tile cost
+// 3.2 K of the tile's 33 K cycles that way.
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (u32)v;
+}
+// Sum over the wave, returned in every lane.
+__device__ __forceinline__ u32 wave_sum(u32 x)
+{
+    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
+}
+
 // In-place exclusive scan of arr[0..n) in LDS by NT threads; returns the total.  The caller has
 // synchronised before the call; the function synchronises before returning.
 template <int NT>
@@ -53,22 +105,16 @@ __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (n <= NT) {                          // one element per thread: no per-thread loops
-        u32 v = tid < n ? arr[tid] : 0, inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            u32 t = __shfl_up(inc, off);
-            if (lane >= off)
-                inc += t;
-        }
+        const u32 v = tid < n ? arr[tid] : 0;
+        const u32 inc = wave_incl_scan(v);
         if (lane == 63)
             wtmp[wave] = inc;
         __syncthreads();
+        // every wave scans the (at most 16) wave totals itself: one LDS read, one DPP scan
+        const u32 ws = wave_incl_scan(lane < NT / 64 ? wtmp[lane] : 0u);
         const int wv1 = __builtin_amdgcn_readfirstlane(wave);
-        u32 wbase1 = 0, total1 = 0;
-        for (int w = 0; w < wv1; w++)
-            wbase1 += wtmp[w];
-        for (int w = 0; w < NT / 64; w++)
-            total1 += wtmp[w];
+        const u32 total1 = (u32)__builtin_amdgcn_readlane((int)ws, NT / 64 - 1);
+        const u32 wbase1 = wv1 ? (u32)__builtin_amdgcn_readlane((int)ws, wv1 - 1) : 0u;
         if (tid < n)
             arr[tid] = wbase1 + inc - v;
         __syncthreads();
@@ -112,7 +158,7 @@ __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
 // plan: one thread per node decides leaf / split width (see DESIGN.md "level plan")
 __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32 n_nodes, int level,
                                                    u32 chunk_len, u32 *__restrict__ outc,
-                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr)
+                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes)
@@ -135,6 +181,7 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         }
         bits = want;
         if (bits > MAX_SPLIT_BITS) bits = MAX_SPLIT_BITS;
+        if (level >= 1 && bits > l1_cap) bits = l1_cap;
         if (bits > rem) bits = rem;
         if (bits < 1) bits = 1;
     }
@@ -153,8 +200,13 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
 {
     if (n_nodes == 0)
         return hipSuccess;
+    static int l1_cap = 0;
+    if (l1_cap == 0) {
+        const char *e = getenv("DNAGPU_L1_BITS");         // experiment: cap the split width of levels >= 1
+        l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
+    }
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
-                       chunk_len, outc, nch, ctr);
+                       chunk_len, outc, nch, ctr, l1_cap);
     return hipGetLastError();
 }
 
@@ -163,16 +215,20 @@ __global__ __launch_bounds__(256) void fill_chunks_kernel(const Node *__restrict
                                                           const u32 *__restrict__ chunk_base,
                                                           Node *__restrict__ nodes_rw, Chunk *__restrict__ chunks)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one node per blockIdx.x-row of 64 lanes: the lanes share the node's chunks (the dna root alone has thousands)
+    const u32 i = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const u32 lane = threadIdx.x & 63;
     if (i >= n_nodes)
         return;
-    u32 cb = child_base[i], kb = chunk_base[i];
-    nodes_rw[i].child_base = cb;
-    nodes_rw[i].chunk_base = kb;
+    const u32 cb = child_base[i], kb = chunk_base[i];
+    if (lane == 0) {
+        nodes_rw[i].child_base = cb;
+        nodes_rw[i].chunk_base = kb;
+    }
     if (nodes[i].split) {
-        u32 len = nodes[i].len;
-        u32 nc = (len + chunk_len - 1) / chunk_len;
-        for (u32 c = 0; c < nc; c++) {
+        const u32 len = nodes[i].len;
+        const u32 nc = (len + chunk_len - 1) / chunk_len;
+        for (u32 c = lane + blockIdx.y * 64; c < nc; c += 64 * gridDim.y) {
             Chunk ch;
             ch.node = i;
             ch.off = c * chunk_len;
@@ -188,7 +244,7 @@ hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, con
 {
     if (n_nodes == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(fill_chunks_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes,
+    hipLaunchKernelGGL(fill_chunks_kernel, dim3((n_nodes + 3) / 4, n_nodes < 64 ? 16 : 1), dim3(256), 0, s, nodes, n_nodes,
                        chunk_len, child_base, chunk_base, nodes_rw, chunks);
     return hipGetLastError();
 }
@@ -301,12 +357,13 @@ hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunk
 // level_prefix: for every split node and 64-digit group, turn the node's chunk rows into exclusive
 // prefixes over chunks (per digit) and store the per-digit totals in tot[row of the first chunk].
 // Grid = (n_chunks, ROW_STRIDE/64); only the workgroup of a node's first chunk works.
-__global__ __launch_bounds__(256) void level_prefix_kernel(const Node *__restrict__ nodes,
+constexpr int PF_SLICES = 16;                           // chunk slices per digit (threads = 64 digits x slices)
+__global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slices, const Node *__restrict__ nodes,
                                                            const Chunk *__restrict__ chunks, u32 n_chunks,
                                                            u32 chunk_len, u32 *__restrict__ hist,
                                                            u32 *__restrict__ tot)
 {
-    __shared__ u32 part[4][64];
+    __shared__ u32 part[PF_SLICES][64];
     const u32 c0 = blockIdx.x;
     if (c0 >= n_chunks)
         return;
@@ -320,7 +377,7 @@ __global__ __launch_bounds__(256) void level_prefix_kernel(const Node *__restric
         return;
     const u32 nc = (nd.len + chunk_len - 1) / chunk_len;
     const u32 slice = threadIdx.x >> 6;
-    const u32 per = (nc + 3) / 4;
+    const u32 per = (nc + n_slices - 1) / n_slices;
     const u32 cb = slice * per < nc ? slice * per : nc;
     const u32 ce = cb + per < nc ? cb + per : nc;
     const bool live = d < R;
@@ -331,7 +388,7 @@ __global__ __launch_bounds__(256) void level_prefix_kernel(const Node *__restric
     part[slice][threadIdx.x & 63] = sum;
     __syncthreads();
     u32 base = 0, total = 0;
-    for (u32 s = 0; s < 4; s++) {
+    for (u32 s = 0; s < (u32)n_slices; s++) {
         u32 t = part[s][threadIdx.x & 63];
         if (s < slice)
             base += t;
@@ -418,12 +475,14 @@ hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *hist, Node
     return hipGetLastError();
 }
 
-hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 chunk_len,
+hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
                                u32 *hist, u32 *tot, hipStream_t s)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(level_prefix_kernel, dim3(n_chunks, ROW_STRIDE / 64), dim3(256), 0, s, nodes, chunks,
+    // few nodes with many chunks each (the dna root): 16 chunk slices per digit; else 4
+    const int slices = n_split_nodes > 0 && n_chunks / n_split_nodes > 32 ? PF_SLICES : 4;
+    hipLaunchKernelGGL(level_prefix_kernel, dim3(n_chunks, ROW_STRIDE / 64), dim3(64 * slices), 0, s, slices, nodes, chunks,
                        n_chunks, chunk_len, hist, tot);
     return hipGetLastError();
 }
@@ -541,13 +600,52 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
 // lines per wave-instruction.)
 constexpr int WC_THREADS = 1024;
 constexpr int WC_ITEMS_KEYS = 16;                       // 16384 staged keys when the source is a key buffer
-constexpr size_t wc_smem(int items)
+constexpr int WC_PAD_SLOTS = 1024;                      // stage slots beyond the tile: parity padding (see below)
+constexpr size_t wc_smem(int items, int nth = WC_THREADS)
 {
-    return (size_t)WC_THREADS * items * 8 + (size_t)(ROW_STRIDE + 8) * 4 * 5 + 32 * 4;
+    return (size_t)(nth * items + nth) * 8 + (size_t)(nth + 8) * 4 * 5 + 32 * 4;
+}
+typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
+
+// Write-out of a staged tile, two slots (16 bytes) per lane.  Measured with per-phase cycle stamps:
+// with one 8-byte store per lane the write-out was 55 % of the scatter's time and ran at 5.4 B/clk
+// per CU -- the store path is bound by store INSTRUCTIONS, so each lane stores 16 bytes.  For that,
+// every digit's run starts in the stage on the parity of its destination (one padding slot at most
+// before, one after: regions have even starts and sizes), so an even slot pair is a 16-byte aligned
+// pair of the destination whenever both slots belong to the same flushed run.
+// flsh[d] = {delta, e0 | f << 16}: staged slot i of digit d goes to dst[i + delta] while i - e0 < f.
+template <int NTH>
+__device__ __forceinline__ void wc_write_out(const u64 *stage, const u32 *flsh, u32 staged, u64 *__restrict__ dst,
+                                             int shift, u32 dmask, int dbg, u64 lin = 0)
+{
+#pragma unroll 4
+    for (u32 g = threadIdx.x; 2 * g < staged; g += NTH) {
+        const u32 i = 2 * g;
+        const ull2_t kk = *reinterpret_cast<const ull2_t *>(&stage[i]);
+        const u32 d0 = (u32)(kk.x >> shift) & dmask, d1 = (u32)(kk.y >> shift) & dmask;
+        const uint2 f0 = reinterpret_cast<const uint2 *>(flsh)[d0];
+        const uint2 f1 = reinterpret_cast<const uint2 *>(flsh)[d1];
+        const bool v0 = (u32)(i - (f0.y & 0xffffu)) < (f0.y >> 16);
+        const bool v1 = (u32)(i + 1 - (f1.y & 0xffffu)) < (f1.y >> 16);
+        if (dbg & 1)
+            continue;
+        if (dbg & 2) {                              // timing ablation: same bytes, consecutive addresses
+            __builtin_nontemporal_store(kk, reinterpret_cast<ull2_t *>(&dst[lin + i]));
+            continue;
+        }
+        if (v0 && v1 && d0 == d1) {
+            __builtin_nontemporal_store(kk, reinterpret_cast<ull2_t *>(&dst[(u64)(u32)(i + f0.x)]));
+        } else {
+            if (v0)
+                NT_STORE((u64)kk.x, &dst[(u64)(u32)(i + f0.x)]);
+            if (v1)
+                NT_STORE((u64)kk.y, &dst[(u64)(u32)(i + 1 + f1.x)]);
+        }
+    }
 }
 
-template <bool SRC_DNA, int WC_ITEMS>
-__global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
+template <bool SRC_DNA, int WC_ITEMS, int NTH>
+__global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
                                                                          const Chunk *__restrict__ chunks,
                                                                          u32 n_chunks,
                                                                          const u64 *__restrict__ words, u64 n_words,
@@ -557,14 +655,16 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
                                                                          const u32 *__restrict__ hist,
                                                                          const u32 *__restrict__ tot, int dbg)
 {
-    constexpr int WC_TILE = WC_THREADS * WC_ITEMS;
+    constexpr int WC_TILE = NTH * WC_ITEMS;
+    constexpr int TS = NTH + 8;                    // table stride: a workgroup of NTH threads splits on at most NTH digits
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *stage = reinterpret_cast<u64 *>(smem);                          // WC_TILE keys
-    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);     // R + 2 (counts, then offsets)
-    u32 *offs = excl + ROW_STRIDE + 8;                                   // next output index per digit
-    u32 *flsh = offs + ROW_STRIDE + 8;                                   // {delta, limit} per digit (uint2)
-    u32 *curs = flsh + 2 * (ROW_STRIDE + 8);                             // staging cursor per digit
-    u32 *wtmp = curs + ROW_STRIDE + 8;                                   // 16 + carry total
+    constexpr u32 WC_STAGE = WC_TILE + NTH;
+    u64 *stage = reinterpret_cast<u64 *>(smem);                          // WC_STAGE slots
+    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_STAGE * 8);    // R + 2 (counts, then padded offsets)
+    u32 *offs = excl + TS;                                   // next output index per digit
+    u32 *flsh = offs + TS;                                   // {delta, limit} per digit (uint2)
+    u32 *curs = flsh + 2 * TS;                             // staging cursor per digit
+    u32 *wtmp = curs + TS;                                   // 16 + carry total
 
     if (blockIdx.x >= n_chunks)
         return;
@@ -597,8 +697,13 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     // of tile t+1 are requested as soon as tile t is staged, so their latency hides behind tile t's
     // write-out (one workgroup per CU: nobody else would hide it).
     u32 t0 = 0;
-    u32 tn = ch.len < (u32)WC_TILE ? ch.len : (u32)WC_TILE;
-    u32 per = (tn + WC_THREADS - 1) / WC_THREADS;         // dna root: consecutive windows per thread
+    // (a tile leaves room for the parity padding: at most two slots per digit)
+    const u32 room0 = WC_STAGE - 2 * R < (u32)WC_TILE ? WC_STAGE - 2 * R : (u32)WC_TILE;
+    // Odd workgroups open with a half tile: neighbouring CUs then alternate between their LDS phases
+    // and their write-out instead of all storing (and all not storing) at the same time.
+    const u32 first_tile = ((blockIdx.x & 1) && !(dbg & 32)) ? room0 / 2 : room0;
+    u32 tn = ch.len < first_tile ? ch.len : first_tile;
+    u32 per = (tn + NTH - 1) / NTH;         // dna root: consecutive windows per thread
     u64 key[SRC_DNA ? 1 : WC_ITEMS];
     Win16 w;
     if (SRC_DNA) {
@@ -606,11 +711,13 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
     } else {
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
-            u32 i = tid + j * WC_THREADS;
+            u32 i = tid + j * NTH;
             key[SRC_DNA ? 0 : j] = NT_LOAD(&src[i < tn ? i : tn - 1]);
         }
     }
 
+    STAMP_DECL
+    STAMP(0);                                       // prologue: descriptors, first tile's loads issued
     for (;;) {
         const bool last = t0 + tn >= ch.len;
         // digit counters start at the carried count, so ranks of new keys land behind the carry
@@ -619,39 +726,59 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
         if (tid == 0)
             excl[R] = 0;
         __syncthreads();
+        STAMP(1);                                   // counter init + barrier
         // count (non-returning LDS adds: no rank registers are kept); the dna root needs only the
         // windows' digits here: one funnel for all 16
         const u64 dv = SRC_DNA ? dig16_load(words, n_words, first + origin + t0 + tid * per, shift) : 0;
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
-            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
+            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * NTH;
             u32 d = SRC_DNA ? (u32)(dv >> (2 * j)) & dmask : (u32)(key[SRC_DNA ? 0 : j] >> shift) & dmask;
             if (i < tn)                             // (no dummy digit: same-address LDS atomics serialise)
                 atomicAdd(&excl[d], 1u);
         }
         __syncthreads();
+        STAMP(2);                                   // count (incl. waiting for the tile's keys)
+        // digit d's region: even start, even size, first key on the parity of its destination
+        u32 m = 0, par = 0, e0 = 0;
+        if (tid < R) {
+            m = excl[tid];                          // carried + new keys of this digit
+            par = (abase + offs[tid]) & 1u;
+            excl[tid] = (m + par + 1u) & ~1u;       // (read back by this thread only: no barrier needed)
+        }
         {
-            const u32 staged_total = block_scan_inplace<WC_THREADS>(excl, (int)R, wtmp);
+            const u32 staged_total = block_scan_inplace<NTH>(excl, (int)R, wtmp);
             if (tid == 0)
                 excl[R] = staged_total;
         }
         // digit d's cursor starts behind its carried keys; thread d re-stages those itself
-        if (tid < R)
-            curs[tid] = excl[tid] + ccnt;
+        if (tid < R) {
+            e0 = excl[tid] + par;
+            curs[tid] = e0 + ccnt;
+        }
         __syncthreads();
-        // place: a returning add on the digit's cursor is the staged slot
+        STAMP(3);                                   // scan + cursors
+        // place: a returning add on the digit's cursor is the staged slot.  All the adds first, then
+        // all the stores: written as one loop, every store waited for its own add's round trip.
+        u32 slot[WC_ITEMS];
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
-            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * WC_THREADS;
+            u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * NTH;
             u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
+            slot[j] = ~0u;
             if (i < tn)
-                stage[atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u)] = kv;
+                slot[j] = atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u);
+        }
+#pragma unroll
+        for (int j = 0; j < WC_ITEMS; j++) {
+            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
+            if (slot[j] != ~0u)
+                stage[slot[j]] = kv;
         }
         __syncthreads();                            // excl[R] (thread 0) and every stage write are visible
-        u32 f = 0, m = 0, e0 = 0;
+        STAMP(4);                                   // place
+        u32 f = 0;
         if (tid < R) {
-            e0 = excl[tid];
-            m = excl[tid + 1] - e0;                 // carried + new keys of this digit
 #pragma unroll
             for (int c = 0; c < 7; c++)
                 if ((u32)c < ccnt)
@@ -659,41 +786,33 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
             const u32 o = offs[tid];
             const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
             f = last ? m : (m >= tail ? m - tail : 0u);
-            // write-out: staged slot i of digit d goes to dst[i + delta] while i < limit
-            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 + f);
+            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 | (f << 16));
         }
         {   // total carried into the next tile
-            u32 cn = m - f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                cn += __shfl_down(cn, off);
+            const u32 cn = wave_sum(m - f);
             if ((tid & 63) == 0 && cn)
                 atomicAdd(sh_carry, cn);
         }
         __syncthreads();
+        STAMP(5);                                   // flush table, carry re-stage
         const u32 t0n = t0 + tn;
-        const u32 room = (u32)WC_TILE - *sh_carry;
+        const u32 room = room0 - *sh_carry;
         const u32 tnn = ch.len - t0n < room ? ch.len - t0n : room;
         if (tnn > 0) {                              // request the next tile's keys now
-            per = (tnn + WC_THREADS - 1) / WC_THREADS;
+            per = (tnn + NTH - 1) / NTH;
             if (SRC_DNA) {
                 w = win16_load(words, n_words, first + origin + t0n + tid * per);
             } else {
 #pragma unroll
                 for (int j = 0; j < WC_ITEMS; j++) {
-                    u32 i = tid + j * WC_THREADS;
+                    u32 i = tid + j * NTH;
                     key[SRC_DNA ? 0 : j] = NT_LOAD(&src[t0n + (i < tnn ? i : tnn - 1)]);
                 }
             }
         }
-        const u32 staged = excl[R];
-#pragma unroll 4
-        for (u32 i = tid; i < staged; i += WC_THREADS) {
-            u64 kv = stage[i];
-            uint2 dl = reinterpret_cast<const uint2 *>(flsh)[(u32)(kv >> shift) & dmask];
-            if (i < dl.y && !(dbg & 1))
-                NT_STORE(kv, &dst[(u64)(u32)(i + dl.x)]);
-        }
+        STAMP(6);                                   // next tile's loads issued
+        wc_write_out<NTH>(stage, flsh, excl[R], dst, shift, dmask, dbg, (origin + t0) & ~(u64)1);
+        STAMP(7);                                   // write-out
         if (tid < R) {
             ccnt = m - f;                           // <= 7
 #pragma unroll
@@ -702,6 +821,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
                     carry[c] = stage[e0 + f + c];
         }
         __syncthreads();
+        STAMP(8);                                   // carry reload + barrier
         if (tid < R)
             offs[tid] += f;
         if (tid == 0)
@@ -711,6 +831,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_kernel(const N
         t0 = t0n;
         tn = tnn;
     }
+    STAMP_FLUSH(SRC_DNA ? 0 : 12);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -729,8 +850,9 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
     constexpr int WC_TILE = WC_THREADS * 16;
     constexpr u32 BATCH = WC_THREADS * 16;        // positions per sweep step: 16 windows per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr u32 WC_STAGE = WC_TILE + WC_PAD_SLOTS;
     u64 *stage = reinterpret_cast<u64 *>(smem);
-    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_TILE * 8);
+    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)WC_STAGE * 8);
     u32 *offs = excl + ROW_STRIDE + 8;
     u32 *flsh = offs + ROW_STRIDE + 8;
     u32 *curs = flsh + 2 * (ROW_STRIDE + 8);
@@ -767,14 +889,16 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
 
     u32 t0 = 0;
     while (t0 < ch.len) {
-        const u32 room = (u32)WC_TILE - *sh_carry;
+        // (room for the parity padding of wc_write_out: at most two slots per digit)
+        const u32 room0 = WC_STAGE - 2 * R < (u32)WC_TILE ? WC_STAGE - 2 * R : (u32)WC_TILE;
+        const u32 room = room0 - *sh_carry;
         const u32 remaining = ch.len - t0;
         u32 P = room * inv;                       // positions of this tile
         if (P > room)
             P = P / BATCH * BATCH;
         if (P > remaining)
             P = remaining;
-        u32 staged_total;
+        u32 staged_total, m = 0, par = 0, e0 = 0;
         for (;;) {
             __syncthreads();                      // previous readers of excl are done
             if (tid < R)
@@ -797,8 +921,13 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
                 }
             }
             __syncthreads();
+            if (tid < R) {                          // even start, even size, first key on its destination's parity
+                m = excl[tid];
+                par = (abase + offs[tid]) & 1u;
+                excl[tid] = (m + par + 1u) & ~1u;
+            }
             staged_total = block_scan_inplace<WC_THREADS>(excl, (int)R, wtmp);
-            if (staged_total <= (u32)WC_TILE || P <= room)
+            if (staged_total <= WC_STAGE || P <= room)
                 break;
             P = P / 2;                            // more keys than room: sweep half as far
             if (P < room)
@@ -809,8 +938,10 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
         const bool last = t0 + P >= ch.len;
         if (tid == 0)
             excl[R] = staged_total;
-        if (tid < R)
-            curs[tid] = excl[tid] + ccnt;
+        if (tid < R) {
+            e0 = excl[tid] + par;
+            curs[tid] = e0 + ccnt;
+        }
         __syncthreads();
         for (u32 b = 0; b < P; b += BATCH) {      // place sweep: same windows, same filter
             const u32 bl = P - b < BATCH ? P - b : BATCH;
@@ -835,10 +966,8 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
             }
         }
         __syncthreads();
-        u32 f = 0, m = 0, e0 = 0;
+        u32 f = 0;
         if (tid < R) {
-            e0 = excl[tid];
-            m = excl[tid + 1] - e0;                 // carried + new keys of this digit
 #pragma unroll
             for (int c = 0; c < 7; c++)
                 if ((u32)c < ccnt)
@@ -846,24 +975,15 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
             const u32 o = offs[tid];
             const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
             f = last ? m : (m >= tail ? m - tail : 0u);
-            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 + f);
+            reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 | (f << 16));
         }
         {   // total carried into the next tile
-            u32 cn = m - f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                cn += __shfl_down(cn, off);
+            const u32 cn = wave_sum(m - f);
             if ((tid & 63) == 0 && cn)
                 atomicAdd(sh_carry, cn);
         }
         __syncthreads();
-#pragma unroll 4
-        for (u32 i = tid; i < staged_total; i += WC_THREADS) {
-            u64 kv = stage[i];
-            uint2 dl = reinterpret_cast<const uint2 *>(flsh)[(u32)(kv >> shift) & dmask];
-            if (i < dl.y && !(dbg & 1))
-                NT_STORE(kv, &dst[(u64)(u32)(i + dl.x)]);
-        }
+        wc_write_out<WC_THREADS>(stage, flsh, staged_total, dst, shift, dmask, dbg);
         if (tid < R) {
             ccnt = m - f;                           // <= 7
 #pragma unroll
@@ -916,13 +1036,18 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
     const u64 mask = kmer_mask(k);
     if (variant == 0 || (src_dna && flt_span != ~0u)) {     // the owner filter lives in the dna root kernel
         static bool attr_set = false;
+        static int nth_keys = 1024;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_dna_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(16));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS, 512));
+            const char *e = getenv("DNAGPU_WC_NTH");      // experiment: 512-thread workgroups (needs splits <= 9 bits)
+            nth_keys = e ? atoi(e) : 1024;
             attr_set = true;
         }
         static int wdbg = -1;
@@ -934,13 +1059,21 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
             hipLaunchKernelGGL(level_scatter_wc_dna_kernel, dim3(n_chunks), dim3(WC_THREADS), wc_smem(16), s, nodes,
                                chunks, n_chunks, words, n_words, first, mask, buf0, hist, tot, flt, wdbg);
         else if (src_dna)                         // unfiltered root: one position per staged key, next tile
-            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS>), dim3(n_chunks), dim3(WC_THREADS),
+            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                               buf1, hist, tot, wdbg);
+        else if (nth_keys == 512)
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512>), dim3(n_chunks), dim3(512),
+                               wc_smem(WC_ITEMS_KEYS, 512), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
         else
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS>), dim3(n_chunks), dim3(WC_THREADS),
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
+#ifdef DNAGPU_STAMPS
+        if (!(src_dna && flt_span != ~0u))
+            stamps_report(src_dna ? "scatter_wc<dna>" : "scatter_wc<keys>", src_dna ? 0 : 12, s);
+#endif
         return hipGetLastError();
     }
     switch (variant) {

@@ -888,7 +888,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
                                   dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
                                   src_dna ? flt_span : ~0u, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
-        HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, chunk_len, hist, tot, st));
+        HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st));
         HIP_TRY(launch_level_children(cur, n_nodes, tot, next, st));
         if (src_dna) {
             // the dna root's children say how many keys survive the owner filter
@@ -994,6 +994,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             }
         }
         if (rc == DNAGPU_OK) {
+            h->total = tr.n_keys;               // rows counted (an owner filter keeps only this owner's rows)
             h->n_distinct = total_groups;
             h->keys = ok;
             h->counts = oc;
@@ -1032,17 +1033,7 @@ extern "C" int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, 
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, owner, n_owners);
-    if (rc == DNAGPU_OK && n_owners > 1) {
-        // rows owned = sum(count) over the groups: computed on the device
-        u64 total = 0;
-        rc = dnagpu_hist_summary(ctx, *out, &total, nullptr, nullptr);
-        if (rc == DNAGPU_OK)
-            (*out)->total = total;
-        else
-            dnagpu_hist_free(ctx, *out);
-    }
-    return rc;
+    return count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, owner, n_owners);
 }
 
 extern "C" int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out)

@@ -84,7 +84,7 @@ hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunk
                              const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, hipStream_t s);
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
-hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 chunk_len,
+hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
                                u32 *hist, u32 *tot, hipStream_t s);
 // per node: leaf -> copied to the next list; split -> totals scanned over digits, children appended
 // in digit (= key) order, tot row overwritten with each digit's absolute base
