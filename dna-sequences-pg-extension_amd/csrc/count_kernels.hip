@@ -644,7 +644,7 @@ __device__ __forceinline__ void wc_write_out(const u64 *stage, const u32 *flsh, 
     }
 }
 
-template <bool SRC_DNA, int WC_ITEMS, int NTH>
+template <bool SRC_DNA, int WC_ITEMS, int NTH, int FLUSH>
 __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__restrict__ nodes,
                                                                          const Chunk *__restrict__ chunks,
                                                                          u32 n_chunks,
@@ -680,17 +680,17 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
     const u64 origin = (u64)nd.start + ch.off;
     const u64 *__restrict__ src = SRC_DNA ? nullptr : (((nd.meta & NODE_BUF) ? buf1 : buf0) + origin);
     u64 *__restrict__ dst = SRC_DNA ? buf0 : ((nd.meta & NODE_BUF) ? buf0 : buf1);
-    const u32 abase = (u32)((reinterpret_cast<uintptr_t>(dst) >> 3) & 7u);   // 64-byte phase of the buffer
+    const u32 abase = (u32)((reinterpret_cast<uintptr_t>(dst) >> 3) & (u32)(FLUSH - 1));   // phase of the buffer inside a flush unit
     u32 *sh_carry = wtmp + 16;                    // carried keys in total (sets the next tile's size)
 
     if (tid < R)
         offs[tid] = hist[(u64)blockIdx.x * ROW_STRIDE + tid] + tot[(u64)nd.chunk_base * ROW_STRIDE + tid];
     if (tid == 0)
         *sh_carry = 0;
-    u64 carry[7];
+    u64 carry[FLUSH - 1];
     u32 ccnt = 0;
 #pragma unroll
-    for (int c = 0; c < 7; c++)
+    for (int c = 0; c < FLUSH - 1; c++)
         carry[c] = 0;
 
     // A tile = the carried keys + as many new keys as still fit the 16,384-slot stage.  The new keys
@@ -780,11 +780,11 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
         u32 f = 0;
         if (tid < R) {
 #pragma unroll
-            for (int c = 0; c < 7; c++)
+            for (int c = 0; c < FLUSH - 1; c++)
                 if ((u32)c < ccnt)
                     stage[e0 + c] = carry[c];
             const u32 o = offs[tid];
-            const u32 tail = (abase + o + m) & 7u;  // keys past the last 64-byte boundary
+            const u32 tail = (abase + o + m) & (u32)(FLUSH - 1);  // keys past the last flush-unit boundary
             f = last ? m : (m >= tail ? m - tail : 0u);
             reinterpret_cast<uint2 *>(flsh)[tid] = make_uint2(o - e0, e0 | (f << 16));
         }
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
         if (tid < R) {
             ccnt = m - f;                           // <= 7
 #pragma unroll
-            for (int c = 0; c < 7; c++)
+            for (int c = 0; c < FLUSH - 1; c++)
                 if ((u32)c < ccnt)
                     carry[c] = stage[e0 + f + c];
         }
@@ -1040,12 +1040,14 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_dna_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(16));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS, 512));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
             const char *e = getenv("DNAGPU_WC_NTH");      // experiment: 512-thread workgroups (needs splits <= 9 bits)
             nth_keys = e ? atoi(e) : 1024;
             attr_set = true;
@@ -1059,15 +1061,19 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
             hipLaunchKernelGGL(level_scatter_wc_dna_kernel, dim3(n_chunks), dim3(WC_THREADS), wc_smem(16), s, nodes,
                                chunks, n_chunks, words, n_words, first, mask, buf0, hist, tot, flt, wdbg);
         else if (src_dna)                         // unfiltered root: one position per staged key, next tile
-            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024>), dim3(n_chunks), dim3(WC_THREADS),
+            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
+                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                               buf1, hist, tot, wdbg);
+        else if (nth_keys == 16)                  // experiment: 128-byte flush units
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
         else if (nth_keys == 512)
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512>), dim3(n_chunks), dim3(512),
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>), dim3(n_chunks), dim3(512),
                                wc_smem(WC_ITEMS_KEYS, 512), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
         else
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024>), dim3(n_chunks), dim3(WC_THREADS),
+            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
 #ifdef DNAGPU_STAMPS
@@ -1097,6 +1103,85 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 // measured: on this chip its cross-XCD look-back cost 35-50 % of the kernel).  Leaves therefore land
 // in completion order; inside a leaf groups ascend, and the segment directory (seg_off/seg_cnt, in
 // leaf = key order) gives the globally ascending view that dnagpu_hist_download serves.
+// The in-bin ranking of leaves_kernel.  Thread t takes the keys staged at positions t + j*NT (its
+// neighbours in the wave hold the neighbouring positions, so the LDS reads below are conflict-free)
+// and returns in key[j] / pos[j] the key and its sorted position: the bin's start + the members
+// that precede it in (key, staged position) order.
+//   * Straight-line code: all rows' keys, then all bin bounds, then four members of every bin are
+//     read as three batches; a loop per key paid one LDS round trip per member and key, one after
+//     the other (cycle stamps: 27 % of the kernel).  Bins of more than four members (0.6 % of the
+//     keys of a random leaf) finish in a loop.
+//   * A member slot past the bin's end reads the key's own slot, which never precedes itself: no
+//     validity masks.  A row past the leaf's end takes the last key and is never written back.
+//   * T = u32 (members of a bin differ only below bit 32): "precedes" is ONE 64-bit compare of
+//     {low dword, staged position} pairs.
+template <int NT, int ITEMS, typename T>
+__device__ __forceinline__ void rank_in_bins(const u64 *A, const u32 *H, const u32 *uniform_bits, u32 len, int sshift,
+                                             u32 smask, u32 nbig, u64 (&key)[ITEMS], u32 (&pos)[ITEMS])
+{
+    const int tid = threadIdx.x;
+    u32 lo[ITEMS], size[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const u32 i = tid + j * NT;
+        key[j] = A[i < len ? i : len - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const u32 b = (u32)(key[j] >> sshift) & smask;
+        const u32 l = H[b], h = H[b + 1];
+        lo[j] = l;
+        size[j] = h - l;
+    }
+    if (nbig > 0) {                                 // rare: a long bin of equal keys keeps its staged order
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 b = (u32)(key[j] >> sshift) & smask;
+            if ((uniform_bits[b >> 5] >> (b & 31)) & 1) {
+                lo[j] = tid + j * NT;
+                size[j] = 0;
+            }
+        }
+    }
+    u32 more = 0;                                   // bit j: row j's bin has more than four members
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const u32 i = tid + j * NT < len ? tid + j * NT : len - 1;
+        T o[4];
+        u32 idx[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            idx[t] = (u32)t < size[j] ? lo[j] + t : i;
+            o[t] = *reinterpret_cast<const T *>(&A[idx[t]]);     // (little endian: low dword first)
+        }
+        u32 cnt = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (sizeof(T) == 4)
+                cnt += (((u64)o[t] << 32) | idx[t]) < (((u64)(u32)key[j] << 32) | i) ? 1u : 0u;
+            else
+                cnt += ((u64)o[t] < key[j] || ((u64)o[t] == key[j] && idx[t] < i)) ? 1u : 0u;
+        }
+        pos[j] = lo[j] + cnt;
+        more |= size[j] > 4 ? (1u << j) : 0u;
+    }
+    if (more) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            if ((more >> j) & 1) {
+                const u32 i = tid + j * NT < len ? tid + j * NT : len - 1;
+                u32 cnt = 0;
+#pragma unroll 1
+                for (u32 m = lo[j] + 4; m < lo[j] + size[j]; m++) {
+                    const u64 o = A[m];
+                    cnt += (o < key[j]) || (o == key[j] && m < i);
+                }
+                pos[j] += cnt;
+            }
+        }
+    }
+}
+
 template <int NT, int MINW>
 __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                           const u64 *__restrict__ buf0,
@@ -1141,11 +1226,13 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         }
     }
 
+    STAMP_DECL
     for (;;) {
         const u32 ln = li + gridDim.x;
         const bool has_next = ln < n_leaves;
         const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
         __syncthreads();                           // A/H of the previous leaf are dead
+        STAMP(0);  // waited for the previous leaf / descriptor
         const u32 len = nd.len;
         const int rem = (int)(nd.meta & 0xff);
         u32 D = 0;                                 // groups in this leaf
@@ -1163,6 +1250,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             if (tid == 0)
                 big_n = 0;
             __syncthreads();
+            STAMP(1);  // zero bins
             u32 rank[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
@@ -1174,6 +1262,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     rank[j] = atomicAdd(&H[(u32)(key[j] >> sshift) & smask], 1u);
             }
             __syncthreads();
+            STAMP(2);  // count (incl. waiting for the keys)
             {   // exclusive scan of the bins, BPT consecutive bins per thread (16-byte LDS accesses)
                 uint4 v[BPT / 4];
                 u32 sum = 0, cmax = 0;
@@ -1185,20 +1274,17 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 }
                 if (cmax > BIG_BIN)                 // rare: some bin holds many copies of few keys
                     big_n = 1;                      // (benign race: every writer stores 1)
-                u32 inc = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    u32 t = __shfl_up(inc, off);
-                    if (lane >= off)
-                        inc += t;
-                }
+                const u32 inc = wave_incl_scan(sum);
                 if (lane == 63)
                     wtmp[wave] = inc;
                 __syncthreads();
                 u32 base = inc - sum;
-                const int wv = __builtin_amdgcn_readfirstlane(wave);
-                for (int w = 0; w < wv; w++)
-                    base += wtmp[w];
+                {   // every wave scans the wave totals itself: one LDS read + one DPP scan
+                    const u32 ws = wave_incl_scan(lane < WAVES ? wtmp[lane] : 0u);
+                    const int wv = __builtin_amdgcn_readfirstlane(wave);
+                    if (wv)
+                        base += (u32)__builtin_amdgcn_readlane((int)ws, wv - 1);
+                }
 #pragma unroll
                 for (int q = 0; q < BPT / 4; q++) {
                     uint4 o;
@@ -1213,6 +1299,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     H[BINS] = len;
             }
             __syncthreads();
+            STAMP(3);  // scan
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
@@ -1220,6 +1307,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     A[H[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
             }
             __syncthreads();
+            STAMP(4);  // place
             const bool any_big = big_n != 0;           // (written before the scan's barriers)
             u32 nbig = 0;
             if (rem > sb && any_big) {
@@ -1252,42 +1340,29 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 __syncthreads();
             }
             if (rem > sb && !(dbg & 1)) {
-                // exact rank inside each (small) bin: #smaller + #equal-before
-                // (walking a thread's eight slots in lock-step instead was measured: 9 % slower)
-#pragma unroll
-                for (int j = 0; j < ITEMS; j++) {
-                    u32 i = tid + j * NT;
-                    if (i < len) {
-                        u64 kv = A[i];
-                        key[j] = kv;
-                        u32 b = (u32)(kv >> sshift) & smask;
-                        u32 b0 = H[b], b1 = H[b + 1];
-                        u32 r = b0;
-                        if (nbig > 0 && ((uniform_bits[b >> 5] >> (b & 31)) & 1)) {
-                            r = i;                 // all members equal: the staged order stands
-                            b1 = b0;
-                        }
-#pragma unroll 1
-                        for (u32 m = b0; m < b1; m++) {
-                            u64 o = A[m];
-                            r += (o < kv) || (o == kv && m < i);
-                        }
-                        rank[j] = r;
-                    }
-                }
+                // exact position inside each (small) bin: thread i ranks the key staged at i
+                if (sshift <= 32)
+                    rank_in_bins<NT, ITEMS, u32>(A, H, uniform_bits, len, sshift, smask, nbig, key, rank);
+                else
+                    rank_in_bins<NT, ITEMS, u64>(A, H, uniform_bits, len, sshift, smask, nbig, key, rank);
                 __syncthreads();
+                STAMP(5);  // in-bin rank
 #pragma unroll
                 for (int j = 0; j < ITEMS; j++)
                     if (tid + j * NT < len)
                         A[rank[j]] = key[j];
                 __syncthreads();
+                STAMP(6);  // write back sorted
             }
         }
 
         // ---- the sort no longer needs key[]: start the next leaf's loads (they land while this
-        // leaf's heads, placement and output run)
-        if (has_next && nn.len > 0 && (nn.meta & 0xff) != 0 && !(nn.meta & NODE_TERMINAL)) {
-            const u64 *__restrict__ nsrc = ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start;
+        // leaf's heads, placement and output run).  Wave 0 issues its share only after the
+        // placement atomic below: a wave's vector-memory operations complete in order, so an atomic
+        // issued behind eight HBM loads would wait for all of them.
+        const bool next_loads = has_next && nn.len > 0 && (nn.meta & 0xff) != 0 && !(nn.meta & NODE_TERMINAL);
+        const u64 *__restrict__ nsrc = ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start;
+        if (next_loads && wave != 0) {
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
@@ -1295,45 +1370,57 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             }
         }
 
-        if (single) {
-            D = 1;
-        } else if (sorted_path) {
-            // run heads in sorted order; row j = positions [j*NT, (j+1)*NT)
+        u64 ob_reg = 0;                            // wave 0, lane 63: the leaf's output base
+        if (sorted_path) {
+            // run heads in sorted order; row j = positions [j*NT, (j+1)*NT).  All the reads first.
+            u64 cur[ITEMS], prv[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
-                u32 i = tid + j * NT;
-                bool head = (i < len) & ((i == 0) | (A[i] != A[i ? i - 1 : 0]));
+                const u32 i = tid + j * NT;
+                cur[j] = A[i];
+                prv[j] = A[i ? i - 1 : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const u32 i = tid + j * NT;
+                const bool head = (i < len) & ((i == 0) | (cur[j] != prv[j]));
                 headbits |= head ? (1u << j) : 0u;
-                u64 hbj = __ballot(head);
+                const u64 hbj = __ballot(head);
                 if (lane == 0)
                     rowcnt[j * WAVES + wave] = (u32)__popcll(hbj);
             }
             __syncthreads();
-            if (wave == 0) {
-                u32 v = rowcnt[lane], inc = v;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    u32 t = __shfl_up(inc, off);
-                    if (lane >= off)
-                        inc += t;
-                }
-                rowcnt[lane] = inc - v;
-                if (lane == 63)
-                    sh_D = inc;
-            }
-            __syncthreads();
-            D = sh_D;
+            STAMP(7);  // next loads issued + heads + ballots
         }
-        // ---- placement: one atomic per leaf (its latency overlaps the head-position fill below)
-        if (tid == 0) {
-            u64 ob = 0;
-            if (D > 0)
-                ob = (dbg & 2) ? (u64)nd.start : (u64)atomicAdd(cursor, (unsigned long long)D);
-            sh_obase = ob;
-            seg_off[li] = ob;
-            seg_cnt[li] = D;
+        if (wave == 0) {
+            if (sorted_path) {
+                const u32 v = rowcnt[lane];
+                const u32 inc = wave_incl_scan(v);
+                rowcnt[lane] = inc - v;
+                D = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            } else if (single) {
+                D = 1;
+            }
+            // ---- placement: one atomic per leaf, issued as early as D is known; its result is
+            // only needed at the last barrier before the output
+            if (lane == 63) {
+                sh_D = D;
+                if (D > 0)
+                    ob_reg = (dbg & 2) ? (u64)nd.start : (u64)atomicAdd(cursor, (unsigned long long)D);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // (keep the atomic ahead of this wave's loads)
+            if (next_loads) {
+#pragma unroll
+                for (int j = 0; j < ITEMS; j++) {
+                    u32 i = tid + j * NT;
+                    key[j] = NT_LOAD(&nsrc[i < nn.len ? i : nn.len - 1]);
+                }
+            }
         }
         if (sorted_path) {
+            __syncthreads();
+            STAMP(8);  // row scan
+            D = sh_D;
             const u64 below = ((u64)1 << lane) - 1;
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
@@ -1346,7 +1433,14 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 H[D] = len;
             // (H as bin offsets is dead: every read of it happened before the barriers above)
         }
+        if (wave == 0 && lane == 63) {
+            sh_obase = ob_reg;
+            seg_off[li] = ob_reg;
+            seg_cnt[li] = D;
+        }
         __syncthreads();
+        STAMP(9);  // atomic + head positions
+        D = sh_D;
         const u64 obase = sh_obase;
         if (!(dbg & 4)) {
             if (single) {
@@ -1362,11 +1456,13 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 }
             }
         }
+        STAMP(10);  // output
         if (!has_next)
             break;
         li = ln;
         nd = nn;
     }
+    STAMP_FLUSH(0);
 }
 
 static u32 leaves_grid(u32 n_leaves, int per_cu)
@@ -1394,7 +1490,7 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, cons
         const char *e = getenv("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
         dbg = e ? atoi(e) : 0;
         const char *v = getenv("DNAGPU_LEAVES_VARIANT");
-        variant = v ? atoi(v) : 3;                       // 512 threads x 8 keys, 87 VGPRs, no scratch: 2 workgroups per CU
+        variant = v ? atoi(v) : 0;                       // 1024 threads x 4 keys, 64 VGPRs: 2 workgroups = 32 waves per CU
         const char *m = getenv("DNAGPU_LEAVES_GRIDMULT");
         mult = m ? atoi(m) : 1;
         if (mult < 1)
@@ -1413,6 +1509,9 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, cons
     else
         hipLaunchKernelGGL((leaves_kernel<1024, 8>), dim3(leaves_grid(n_leaves, 2 * mult)), dim3(1024), 0, s, leaves,
                            n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+#ifdef DNAGPU_STAMPS
+    stamps_report("leaves", 0, s);
+#endif
     return hipGetLastError();
 }
 

@@ -32,6 +32,12 @@ __global__ __launch_bounds__(256) void k_write(uint64_t *dst, uint64_t n)
     for (uint64_t i = gid; i < n; i += stride)
         __builtin_nontemporal_store(i, &dst[i]);
 }
+__global__ __launch_bounds__(1024) void k_write_wg1024(uint64_t *dst, uint64_t n)
+{
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = gid; i < n; i += stride)
+        __builtin_nontemporal_store(i, &dst[i]);
+}
 __global__ __launch_bounds__(256) void k_copy8(const uint64_t *src, uint64_t *dst, uint64_t n)
 {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
@@ -45,16 +51,18 @@ __global__ __launch_bounds__(256) void k_copy16(const ull2_t *src, ull2_t *dst, 
     for (uint64_t i = gid; i < n2; i += stride)
         __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
-// reads n keys sequentially; every run of run_keys consecutive keys is stored, aligned, at a random run slot
-__global__ __launch_bounds__(256) void k_scat(const uint64_t *src, uint64_t *dst, uint64_t n, int run_keys, int read_too)
+// reads n keys sequentially; every run of 2^run_log consecutive keys is stored, aligned, at a random run slot
+// (shifts and masks only: a 64-bit division per key would make this ALU-bound)
+__global__ __launch_bounds__(256) void k_scat(const uint64_t *src, uint64_t *dst, uint64_t n, int run_log, int read_too)
 {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t n_runs = n / run_keys;
+    const uint64_t run_mask = ((uint64_t)1 << run_log) - 1;
+    const uint64_t n_runs_mask = (((uint64_t)1 << 31) >> run_log) - 1;       // power-of-two run slots inside 2^31 keys
     for (uint64_t i = gid; i < n; i += stride) {
         uint64_t v = read_too ? __builtin_nontemporal_load(&src[i]) : i;
-        uint64_t run = i / run_keys, within = i % run_keys;
-        uint64_t where = mix(run) % n_runs;
-        __builtin_nontemporal_store(v, &dst[where * run_keys + within]);
+        uint64_t run = i >> run_log, within = i & run_mask;
+        uint64_t where = mix(run) & n_runs_mask;
+        __builtin_nontemporal_store(v, &dst[(where << run_log) + within]);
     }
 }
 
@@ -84,14 +92,21 @@ int main()
     dim3 g(256 * 16), t(256);
     run("read 8B/lane", n * 8.0, [&] { hipLaunchKernelGGL(k_read, g, t, 0, 0, a, n, sink); });
     run("write 8B/lane", n * 8.0, [&] { hipLaunchKernelGGL(k_write, g, t, 0, 0, b, n); });
+    // per-CU or chip limit?  the same stores from 1024-thread workgroups on a fraction of the CUs
+    for (int blocks : {32, 64, 128, 256, 512}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "write 8B/lane, %d x 1024 threads", blocks);
+        run(nm, n * 8.0, [&] { hipLaunchKernelGGL(k_write_wg1024, dim3(blocks), dim3(1024), 0, 0, b, n); });
+    }
     run("copy 8B/lane (R+W)", n * 16.0, [&] { hipLaunchKernelGGL(k_copy8, g, t, 0, 0, a, b, n); });
     run("copy 16B/lane (R+W)", n * 16.0, [&] { hipLaunchKernelGGL(k_copy16, g, t, 0, 0, (const ull2_t *)a, (ull2_t *)b, n / 2); });
-    for (int r : {8, 16, 32, 128}) {
+    for (int rl : {2, 3, 4, 5, 7}) {
+        const int r = 1 << rl;
         char nm[64];
         snprintf(nm, sizeof nm, "write scattered runs of %d keys", r);
-        run(nm, n * 8.0, [&] { hipLaunchKernelGGL(k_scat, g, t, 0, 0, a, b, n, r, 0); });
+        run(nm, n * 8.0, [&] { hipLaunchKernelGGL(k_scat, g, t, 0, 0, a, b, n, rl, 0); });
         snprintf(nm, sizeof nm, "read seq + write runs of %d (R+W)", r);
-        run(nm, n * 16.0, [&] { hipLaunchKernelGGL(k_scat, g, t, 0, 0, a, b, n, r, 1); });
+        run(nm, n * 16.0, [&] { hipLaunchKernelGGL(k_scat, g, t, 0, 0, a, b, n, rl, 1); });
     }
     return 0;
 }
