@@ -291,7 +291,34 @@ __device__ __forceinline__ u64 dig16_load(const u64 *__restrict__ words, u64 n_w
 // (d - lo) < span (unsigned) exist; span = ~0 keeps everything.
 struct DigitFilter {
     u32 lo, span;
+    u32 tb;         // > 0: span is a power of two and lo a multiple of it: only the digit's top tb bits decide
 };
+
+// Which of the 16 windows of a dig16_load belong to the owner: bit 2j set = window j kept (j < nvalid).
+// With an aligned power-of-two range (every power-of-two GPU count) the test is bit-parallel: the
+// top tb bits of all 16 digits are compared in 2*tb + 2 operations on the 64-bit funnel, instead of
+// a shift, a mask, a subtract and a compare per window -- the owner sweep visits W times more
+// windows than it keeps, so this test is most of a sharded level 0.
+__device__ __forceinline__ u32 owner_bits16(u64 dv, int bits, u32 dmask, const DigitFilter &flt, u32 nvalid)
+{
+    const u32 vmask = nvalid >= 16 ? 0x55555555u : (u32)(((u64)1 << (2 * nvalid)) - 1) & 0x55555555u;
+    if (flt.tb) {
+        const int sh = bits - (int)flt.tb;
+        const u64 y = dv >> sh;
+        const u32 pat = flt.lo >> sh;
+        u32 m = vmask;
+        for (u32 b = 0; b < flt.tb; b++)
+            m &= ((pat >> b) & 1) ? (u32)(y >> b) : ~(u32)(y >> b);
+        return m;
+    }
+    u32 m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 d = (u32)(dv >> (2 * j)) & dmask;
+        m |= (d - flt.lo < flt.span) ? (1u << (2 * j)) : 0u;
+    }
+    return m & vmask;
+}
 
 // ------------------------------------------------------------------------------------------------
 // level_hist: one workgroup per chunk -> hist[chunk][digit]
@@ -319,11 +346,20 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
     if (SRC_DNA) {
         for (u32 i0 = threadIdx.x * 16; i0 < ch.len; i0 += SC_THREADS * 16) {
             const u64 dv = dig16_load(words, n_words, first + origin + i0, shift);
+            if (flt.span == ~0u) {                  // no owner filter: every window counts
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                u32 d = (u32)(dv >> (2 * j)) & dmask;
-                if (i0 + j < ch.len && d - flt.lo < flt.span)
-                    atomicAdd(&h[d], 1u);
+                for (int j = 0; j < 16; j++) {
+                    u32 d = (u32)(dv >> (2 * j)) & dmask;
+                    if (i0 + j < ch.len)
+                        atomicAdd(&h[d], 1u);
+                }
+            } else {
+                u32 m = owner_bits16(dv, bits, dmask, flt, ch.len - i0);
+                while (m) {
+                    const int j2 = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    atomicAdd(&h[(u32)(dv >> j2) & dmask], 1u);
+                }
             }
         }
     } else {
@@ -339,9 +375,9 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
 
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, hipStream_t s)
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s)
 {
-    const DigitFilter flt{flt_lo, flt_span};
+    const DigitFilter flt{flt_lo, flt_span, flt_tb};
     if (n_chunks == 0)
         return hipSuccess;
     if (src_dna)
@@ -912,12 +948,12 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
                 const u32 bl = P - b < BATCH ? P - b : BATCH;
                 const u32 per = (bl + WC_THREADS - 1) / WC_THREADS;
                 const u64 dv = dig16_load(words, n_words, first + origin + t0 + b + tid * per, shift);
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const u32 i = (u32)j < per ? tid * per + j : bl;
-                    const u32 d = (u32)(dv >> (2 * j)) & dmask;
-                    if (i < bl && d - flt.lo < flt.span)
-                        atomicAdd(&excl[d], 1u);
+                const u32 i0 = tid * per;
+                u32 mk = owner_bits16(dv, bits, dmask, flt, i0 < bl ? (bl - i0 < per ? bl - i0 : per) : 0u);
+                while (mk) {
+                    const int j2 = __ffs((int)mk) - 1;
+                    mk &= mk - 1;
+                    atomicAdd(&excl[(u32)(dv >> j2) & dmask], 1u);
                 }
             }
             __syncthreads();
@@ -948,17 +984,13 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
             const u32 per = (bl + WC_THREADS - 1) / WC_THREADS;
             const u64 pos0 = first + origin + t0 + b + tid * per;
             const u64 dv = dig16_load(words, n_words, pos0, shift);
-            u32 acc = 0;                          // bit j: window j is this owner's
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const u32 i = (u32)j < per ? tid * per + j : bl;
-                const u32 d = (u32)(dv >> (2 * j)) & dmask;
-                acc |= (i < bl && d - flt.lo < flt.span) ? (1u << j) : 0u;
-            }
+            const u32 i0 = tid * per;
+            // bit 2j: window j is this owner's
+            u32 acc = owner_bits16(dv, bits, dmask, flt, i0 < bl ? (bl - i0 < per ? bl - i0 : per) : 0u);
             if (acc) {                            // full keys only for the windows that are kept
                 const Win16 w = win16_load(words, n_words, pos0);
                 while (acc) {
-                    const int j = __ffs((int)acc) - 1;
+                    const int j = (__ffs((int)acc) - 1) >> 1;
                     acc &= acc - 1;
                     const u64 kv = win16_key(w, j, mask);
                     stage[atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u)] = kv;
@@ -1020,11 +1052,11 @@ static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, con
 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
-                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, hipStream_t s)
+                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    const DigitFilter flt{flt_lo, flt_span};
+    const DigitFilter flt{flt_lo, flt_span, flt_tb};
     static int variant = -1;
     if (variant < 0) {
         const char *v = getenv("DNAGPU_SCATTER_VARIANT");

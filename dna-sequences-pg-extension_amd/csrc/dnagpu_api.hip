@@ -814,7 +814,7 @@ struct TreeResult {
 // (keys land in buf0, allocated here); else root over keys_in (used as buf0).
 static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k,
                     u64 *keys_in, int force_bits, TreeResult *res, int fixed_bits = 0, u64 fixed_prefix = 0,
-                    bool single_level = true, u32 flt_lo = 0, u32 flt_span = ~0u)
+                    bool single_level = true, u32 flt_lo = 0, u32 flt_span = ~0u, u32 flt_tb = 0)
 {
     hipStream_t st = ctx->stream;
     u64 *buf0 = keys_in, *buf1 = nullptr;
@@ -886,7 +886,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         prof_mark(ctx, LEVEL_HIST_NAMES[li]);
         HIP_TRY(launch_level_hist(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                   dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
-                                  src_dna ? flt_span : ~0u, st));
+                                  src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
         HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st));
         HIP_TRY(launch_level_children(cur, n_nodes, tot, next, st));
@@ -906,7 +906,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
             prof_mark(ctx, LEVEL_SCATTER_NAMES[li]);
             HIP_TRY(launch_level_scatter(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                          dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot,
-                                         src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, st));
+                                         src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, st));
         }
         ps.free_now(outc);
         ps.free_now(nch);
@@ -953,8 +953,16 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             const u32 R = 1u << obits;
             const u32 d_lo = (u32)(((u64)owner * R + n_owners - 1) / n_owners);
             const u32 d_hi = (u32)(((u64)(owner + 1) * R + n_owners - 1) / n_owners);
-            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo,
-                          d_hi > d_lo ? d_hi - d_lo : 0u);
+            const u32 span = d_hi > d_lo ? d_hi - d_lo : 0u;
+            // aligned power-of-two range (every power-of-two GPU count): the kernels test top bits only
+            u32 tb = 0;
+            if (span && (span & (span - 1)) == 0 && d_lo % span == 0 && span < R) {
+                int lg = 0;
+                while ((1u << lg) < span)
+                    lg++;
+                tb = (u32)(obits - lg);
+            }
+            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo, span, tb);
         } else {
             rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         }

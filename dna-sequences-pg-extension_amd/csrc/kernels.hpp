@@ -78,10 +78,11 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
 hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, const u32 *child_base,
                               const u32 *chunk_base, Node *nodes_rw, Chunk *chunks, hipStream_t s);
 // src_dna != 0: the (single) node being split is the root over the packed sequence; flt_lo/flt_span:
-// owner filter on the root's digits ((d - lo) < span keeps a key; span = ~0 keeps all)
+// owner filter on the root's digits ((d - lo) < span keeps a key; span = ~0 keeps all; tb > 0: lo/span are an
+// aligned power-of-two range and only the digit's top tb bits need testing)
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, hipStream_t s);
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s);
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
@@ -91,7 +92,7 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
 hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *tot, Node *next, hipStream_t s);
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
-                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, hipStream_t s);
+                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s);
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
