@@ -154,7 +154,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 3),
-                        "traffic": load_traffic(dom)}
+                        # PMC traffic was collected for the default single-GPU workload only
+                        "traffic": load_traffic(dom) if (world == 1 and n_bases == 3_000_000_000 and k == 31) else None}
         b_in = 8 * ((n_bases + 31) // 32)
         t_step = elapsed / args.steps
         job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS / world, 5),
