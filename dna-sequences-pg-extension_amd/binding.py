@@ -73,6 +73,10 @@ def lib():
     L.dnagpu_dna_pack.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(vp), u64p, C.c_char_p]
     L.dnagpu_dna_unpack.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, C.c_int]
     L.dnagpu_kmers_to_text.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_int]
+    L.dnagpu_dna_wire_size.argtypes = [C.c_uint64]
+    L.dnagpu_dna_wire_size.restype = C.c_uint64
+    L.dnagpu_dna_from_wire.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.dnagpu_dna_to_wire.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.dnagpu_dna_length.argtypes = [vp]
     L.dnagpu_dna_length.restype = C.c_uint64
     L.dnagpu_dna_device_words.argtypes = [vp]
@@ -298,6 +302,20 @@ class Context:
         buf = C.create_string_buffer(max(count, 1))
         _chk(lib().dnagpu_dna_unpack(self.h, dna.h, first, count, buf, 0))
         return buf.raw[:count].decode()
+
+    def from_wire(self, wire):
+        """dna_recv on the device: the binary wire image (bytes) -> Dna"""
+        b = bytes(wire)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_dna_from_wire(self.h, b, len(b), 0, C.byref(h)))
+        return Dna(self, h)
+
+    def to_wire(self, dna):
+        """dna_send on the device: Dna -> the binary wire image (bytes)"""
+        n = lib().dnagpu_dna_wire_size(dna.n_bases)
+        buf = C.create_string_buffer(int(n))
+        _chk(lib().dnagpu_dna_to_wire(self.h, dna.h, buf, n, 0))
+        return buf.raw
 
     def kmers_to_text(self, keys, k):
         a = np.ascontiguousarray(keys, dtype=np.uint64)

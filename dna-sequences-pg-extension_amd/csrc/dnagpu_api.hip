@@ -502,6 +502,92 @@ extern "C" int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_
     return DNAGPU_OK;
 }
 
+extern "C" uint64_t dnagpu_dna_wire_size(uint64_t n_bases) { return 8 + 8 * words_for(n_bases); }
+
+extern "C" int dnagpu_dna_from_wire(dnagpu_ctx *ctx, const void *wire, uint64_t wire_bytes, int wire_on_device,
+                                    dnagpu_dna **out)
+{
+    if (!ctx || !wire || !out || wire_bytes < 8)
+        return DNAGPU_ERR_BAD_ARG;
+    if (wire_on_device && (reinterpret_cast<uintptr_t>(wire) & 7))
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned char hdr[8];
+    if (wire_on_device) {
+        HIP_TRY(hipMemcpyAsync(hdr, wire, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+        memcpy(hdr, wire, 8);
+    }
+    u64 n_bases = 0;
+    for (int i = 0; i < 8; i++)
+        n_bases = (n_bases << 8) | hdr[i];                  // pq_getmsgint64: network byte order (dna.c:251)
+    if (n_bases == 0)
+        return DNAGPU_ERR_DNA_EMPTY;
+    if (n_bases > ((u64)1 << 40) || wire_bytes != dnagpu_dna_wire_size(n_bases))
+        return DNAGPU_ERR_BAD_ARG;
+    const u64 nw = words_for(n_bases);
+    u64 *d = nullptr;
+    RC_TRY(pool_alloc_t(ctx, (size_t)nw, &d));
+    int rc = DNAGPU_OK;
+    {
+        PoolScope ps(ctx);
+        const u64 *src = reinterpret_cast<const u64 *>(static_cast<const unsigned char *>(wire) + 8);
+        u64 *stage = nullptr;
+        hipError_t e = hipSuccess;
+        if (!wire_on_device) {
+            rc = ps.alloc((size_t)nw, &stage);
+            if (rc == DNAGPU_OK)
+                e = hipMemcpyAsync(stage, src, nw * 8, hipMemcpyHostToDevice, ctx->stream);
+            src = stage;
+        }
+        const u64 last_mask = (n_bases % 32) ? (((u64)1 << (2 * (n_bases % 32))) - 1) : ~(u64)0;
+        if (rc == DNAGPU_OK && e == hipSuccess)
+            e = launch_wire_swap(src, d, nw, last_mask, ctx->stream);
+        if (rc == DNAGPU_OK && e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (rc == DNAGPU_OK && e != hipSuccess) {
+            set_err("from_wire: %s", hipGetErrorString(e));
+            rc = DNAGPU_ERR_HIP;
+        }
+    }
+    dnagpu_dna *h = rc == DNAGPU_OK ? new (std::nothrow) dnagpu_dna{d, nw, n_bases, true} : nullptr;
+    if (!h) {
+        pool_free(ctx, d);
+        return rc == DNAGPU_OK ? DNAGPU_ERR_OOM : rc;
+    }
+    *out = h;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_dna_to_wire(dnagpu_ctx *ctx, const dnagpu_dna *dna, void *wire, uint64_t wire_cap,
+                                  int wire_on_device)
+{
+    if (!ctx || !dna || !wire || wire_cap < dnagpu_dna_wire_size(dna->n_bases))
+        return DNAGPU_ERR_BAD_ARG;
+    if (wire_on_device && (reinterpret_cast<uintptr_t>(wire) & 7))
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned char hdr[8];
+    for (int i = 0; i < 8; i++)
+        hdr[i] = (unsigned char)(dna->n_bases >> (56 - 8 * i));     // pq_sendint64 (dna.c:282, as an int64)
+    const u64 nw = words_for(dna->n_bases);
+    PoolScope ps(ctx);
+    u64 *dst = reinterpret_cast<u64 *>(static_cast<unsigned char *>(wire) + 8);
+    u64 *stage = nullptr;
+    if (!wire_on_device) {
+        RC_TRY(ps.alloc((size_t)std::max<u64>(nw, 1), &stage));
+        memcpy(wire, hdr, 8);
+    } else {
+        HIP_TRY(hipMemcpyAsync(wire, hdr, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(launch_wire_swap(dna->words, wire_on_device ? dst : stage, nw, ~(u64)0, ctx->stream));
+    if (!wire_on_device && nw)
+        HIP_TRY(hipMemcpyAsync(dst, stage, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
 extern "C" int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k, char *out_text,
                                     int on_device)
 {

@@ -383,6 +383,37 @@ hipError_t launch_unpack(const u64 *words, u64 first, u64 count, unsigned char *
     return hipGetLastError();
 }
 
+// dna_recv / dna_send (dna.c:244-291): the wire carries every packed word through pq_sendint64, i.e.
+// byte-swapped on this little-endian machine.  One 16-byte access per lane either way; dna_recv also
+// clears the bits behind the last base (the type's palloc0 invariant, dna.c:186).
+__global__ __launch_bounds__(256) void wire_swap_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 n_words,
+                                                        u64 last_mask)
+{
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n_words)
+        return;
+    u64 a = __builtin_bswap64(src[i]);
+    if (i + 1 < n_words) {
+        u64 b = __builtin_bswap64(src[i + 1]);
+        if (i + 2 == n_words)
+            b &= last_mask;
+        dst[i] = a;
+        dst[i + 1] = b;
+    } else {
+        dst[i] = a & last_mask;
+    }
+}
+
+hipError_t launch_wire_swap(const u64 *src, u64 *dst, u64 n_words, u64 last_mask, hipStream_t s)
+{
+    if (n_words == 0)
+        return hipSuccess;
+    const u64 threads = (n_words + 1) / 2;
+    hipLaunchKernelGGL(wire_swap_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, dst, n_words,
+                       last_mask);
+    return hipGetLastError();
+}
+
 // n keys of k bases -> n records of k characters + NUL (stride k+1), kmer_out's text
 __global__ __launch_bounds__(256) void kmers_to_text_kernel(const u64 *__restrict__ keys, u64 n, int k,
                                                             unsigned char *__restrict__ text)

@@ -32,6 +32,8 @@ hipError_t launch_hist_summary(const u64 *keys, const u32 *counts, u64 n, u64 *r
 hipError_t launch_pack(const unsigned char *text, u64 n_bases, u64 *words, u64 *bad_pos, hipStream_t s);
 hipError_t launch_unpack(const u64 *words, u64 first, u64 count, unsigned char *text, hipStream_t s);
 hipError_t launch_kmers_to_text(const u64 *keys, u64 n, int k, unsigned char *text, hipStream_t s);
+// dst[i] = bswap64(src[i]); the last word is ANDed with last_mask (wire <-> packed words)
+hipError_t launch_wire_swap(const u64 *src, u64 *dst, u64 n_words, u64 last_mask, hipStream_t s);
 
 // exclusive scan of n u32 values (in != out allowed, in == out allowed); *total receives the sum.
 // tmp must hold scan_tmp_words(n) u32 values.

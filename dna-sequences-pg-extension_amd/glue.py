@@ -64,6 +64,14 @@ def lib():
         L.count_kmers_next.argtypes = [vp, C.POINTER(_Kmer), C.POINTER(C.c_int64)]
         L.count_kmers_totals.argtypes = [vp] + [C.POINTER(C.c_int64)] * 3
         L.count_kmers_end.argtypes = [vp]
+        L.dna_send.restype = vp
+        L.dna_send.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.dna_recv.restype = vp
+        L.dna_recv.argtypes = [C.c_char_p, C.c_size_t]
+        L.kmer_send.restype = None
+        L.kmer_send.argtypes = [C.POINTER(_Kmer), C.c_char_p]
+        L.kmer_recv.restype = C.c_bool
+        L.kmer_recv.argtypes = [C.c_char_p, C.POINTER(_Kmer)]
         L.dna_glue_shutdown.restype = None
         _LIB = L
     return _LIB
@@ -88,13 +96,32 @@ def _take_str(p):
 class dna:
     """the `dna` type: dna('ATCG') is dna_in"""
 
-    def __init__(self, text):
-        self.p = lib().dna_in(text.encode())
+    def __init__(self, text=None, p=None):
+        self.p = p if p is not None else lib().dna_in(text.encode())
         if not self.p:
             raise _err()
 
     def __str__(self):
         return _take_str(lib().dna_out(self.p))
+
+    def send(self):
+        """dna_send: the binary wire image"""
+        n = C.c_size_t()
+        buf = lib().dna_send(self.p, C.byref(n))
+        if not buf:
+            raise _err()
+        raw = C.string_at(buf, n.value)
+        _libc.free(buf)
+        return raw
+
+    @classmethod
+    def recv(cls, wire):
+        """dna_recv"""
+        b = bytes(wire)
+        p = lib().dna_recv(b, len(b))
+        if not p:
+            raise _err()
+        return cls(p=p)
 
     def __len__(self):
         return int(lib().dna_length(self.p))
@@ -122,6 +149,18 @@ class kmer:
 
     def __hash__(self):
         return kmer_hash(self)
+
+    def send(self):
+        buf = C.create_string_buffer(12)
+        lib().kmer_send(C.byref(self.c), buf)
+        return buf.raw
+
+    @classmethod
+    def recv(cls, wire):
+        c = _Kmer()
+        if not lib().kmer_recv(bytes(wire), C.byref(c)):
+            raise _err()
+        return cls(c=c)
 
 
 class qkmer:

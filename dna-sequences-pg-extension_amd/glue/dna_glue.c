@@ -110,6 +110,95 @@ char *dna_out(const Dna *dna)
     return s;
 }
 
+/* ---- binary I/O: per-datum host loops like dna_in/dna_out (bulk, device-side: dnagpu_dna_from_wire) ---- */
+static void put_be64(unsigned char *p, uint64_t v)
+{
+    for (int i = 0; i < 8; i++)
+        p[i] = (unsigned char)(v >> (56 - 8 * i));                        /* pq_sendint64 */
+}
+static uint64_t get_be64(const unsigned char *p)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++)
+        v = (v << 8) | p[i];                                              /* pq_getmsgint64 */
+    return v;
+}
+
+/* dna_send (dna.c:270-291) */
+unsigned char *dna_send(const Dna *dna, size_t *wire_bytes)
+{
+    uint64_t bit_length = (dna->length * 2 + 63) / 64;                    /* dna.c:279 */
+    unsigned char *buf = (unsigned char *)malloc(8 + 8 * bit_length);
+    if (!buf) {
+        ereport_error("out of memory");
+        return NULL;
+    }
+    put_be64(buf, dna->length);                                           /* dna.c:282, as an int64 */
+    for (uint64_t i = 0; i < bit_length; i++)                             /* dna.c:284-286 */
+        put_be64(buf + 8 + 8 * i, dna->bit_sequence[i]);
+    *wire_bytes = 8 + 8 * bit_length;
+    return buf;
+}
+
+/* dna_recv (dna.c:244-268) */
+Dna *dna_recv(const unsigned char *wire, size_t wire_bytes)
+{
+    if (wire == NULL || wire_bytes < 8) {
+        ereport_error("insufficient data left in message");               /* pq_getmsgint64's own ERROR */
+        return NULL;
+    }
+    uint64_t length = get_be64(wire);                                     /* dna.c:251 */
+    if (length == 0) {
+        ereport_error("DNA sequence cannot be empty");                    /* the type's invariant, dna.c:161 */
+        return NULL;
+    }
+    uint64_t bit_length = (length * 2 + 63) / 64;                         /* dna.c:252-253 */
+    if (length > ((uint64_t)1 << 40) || wire_bytes != 8 + 8 * bit_length) {
+        ereport_error("insufficient data left in message");
+        return NULL;
+    }
+    Dna *dna = (Dna *)calloc(1, sizeof(Dna));
+    uint64_t *w = (uint64_t *)calloc(bit_length, sizeof(uint64_t));       /* palloc0, dna.c:257 */
+    if (!dna || !w) {
+        free(dna);
+        free(w);
+        ereport_error("out of memory");
+        return NULL;
+    }
+    for (uint64_t i = 0; i < bit_length; i++)                             /* dna.c:263-265 */
+        w[i] = get_be64(wire + 8 + 8 * i);
+    if (length % 32)
+        w[bit_length - 1] &= (((uint64_t)1 << (2 * (length % 32))) - 1);  /* keep the tail bits zero (dna.c:186) */
+    dna->length = length;
+    dna->bit_sequence = w;
+    return dna;
+}
+
+/* kmer_send (dna.c:579-597) */
+void kmer_send(const Kmer *kmer, unsigned char wire[12])
+{
+    uint32_t l = (uint32_t)kmer->length;                                  /* dna.c:588 */
+    wire[0] = (unsigned char)(l >> 24);
+    wire[1] = (unsigned char)(l >> 16);
+    wire[2] = (unsigned char)(l >> 8);
+    wire[3] = (unsigned char)l;
+    put_be64(wire + 4, kmer->bit_sequence);                               /* dna.c:591 */
+}
+
+/* kmer_recv (dna.c:552-574) */
+bool kmer_recv(const unsigned char wire[12], Kmer *out)
+{
+    int32_t length = (int32_t)(((uint32_t)wire[0] << 24) | ((uint32_t)wire[1] << 16) |
+                               ((uint32_t)wire[2] << 8) | wire[3]);       /* dna.c:559 */
+    if (length <= 0 || length > 32) {
+        ereport_error("Invalid K-mer length: must be between 1 and 32");  /* dna.c:566-568 */
+        return false;
+    }
+    out->length = length;
+    out->bit_sequence = get_be64(wire + 4);                               /* dna.c:571 */
+    return true;
+}
+
 void dna_free(Dna *dna)
 {
     if (!dna)

@@ -59,6 +59,15 @@ bool kmer_in(const char *str, Kmer *out);
 char *kmer_out(const Kmer *kmer);       /* malloc'd */
 bool qkmer_in(const char *str, Qkmer *out);
 
+/* ---- binary I/O (dna_recv/dna_send dna.c:244-291, kmer_recv/kmer_send dna.c:552-597) ----
+ * The wire image the reference describes -- length, then the packed words through pq_sendint64 --
+ * with a length field that works (the reference's pq_sendint(.., 8) is rejected by PostgreSQL).
+ * dna: int64 length + ceil(length/32) int64 words, network byte order; kmer: int32 length + int64. */
+unsigned char *dna_send(const Dna *dna, size_t *wire_bytes);       /* malloc'd */
+Dna *dna_recv(const unsigned char *wire, size_t wire_bytes);
+void kmer_send(const Kmer *kmer, unsigned char wire[12]);
+bool kmer_recv(const unsigned char wire[12], Kmer *out);           /* ERROR "Invalid K-mer length: must be between 1 and 32" */
+
 /* ---- per-datum operators (host, as in the reference) ---- */
 bool kmer_eq(const Kmer *a, const Kmer *b);                         /* dna.c:686-696  `=`  */
 bool kmer_ne(const Kmer *a, const Kmer *b);                         /* dna.c:708-720  `<>` */

@@ -102,6 +102,21 @@ int dnagpu_dna_pack(dnagpu_ctx *ctx, const char *text, uint64_t n_bases, int tex
 /* decode_dna (dna.c:135-152): bases [first, first+count) as `count` characters (no NUL). */
 int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t first, uint64_t count,
                       char *out_text, int out_on_device);
+/* ---- binary wire image: dna_recv / dna_send (dna.c:244-268, 270-291) ---------------------------
+ * Wire image of a dna: int64 length in bases, then ceil(length/32) packed words, every field in
+ * network byte order (what pq_sendint64 writes and pq_getmsgint64 reads).  The reference moves its
+ * length field with pq_getmsgint / pq_sendint of size 8, which PostgreSQL rejects ("unsupported
+ * integer size 8"), so its binary I/O cannot work as written; this is the format it describes, with
+ * a length field that does.  from_wire: wire_bytes must equal dnagpu_dna_wire_size(length) else
+ * DNAGPU_ERR_BAD_ARG; length 0 is DNAGPU_ERR_DNA_EMPTY (the type has no empty value, dna.c:160-161);
+ * bits behind the last base are cleared (dna.c:186).  A device-side wire buffer must be 8-byte
+ * aligned. */
+uint64_t dnagpu_dna_wire_size(uint64_t n_bases);
+int dnagpu_dna_from_wire(dnagpu_ctx *ctx, const void *wire, uint64_t wire_bytes, int wire_on_device,
+                         dnagpu_dna **out);
+int dnagpu_dna_to_wire(dnagpu_ctx *ctx, const dnagpu_dna *dna, void *wire, uint64_t wire_cap,
+                       int wire_on_device);
+
 /* decode_kmer / kmer_out (dna.c:428-452, 538-546) for n keys of k bases: n records of k characters
  * followed by a NUL (record stride k+1).  keys and out_text both host, or both device. */
 int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k, char *out_text,

@@ -61,6 +61,14 @@ def lib():
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_synth_words.argtypes = [C.c_uint64, C.c_uint64, u64p]
         L.orc_synth_words_repeat.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u64p]
+        L.orc_dna_wire_size.restype = C.c_uint64
+        L.orc_dna_wire_size.argtypes = [C.c_uint64]
+        L.orc_dna_to_wire.argtypes = [u64p, C.c_uint64, C.c_void_p]
+        L.orc_dna_to_wire.restype = None
+        L.orc_dna_from_wire.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p]
+        L.orc_kmer_to_wire.argtypes = [C.c_int32, C.c_uint64, C.c_void_p]
+        L.orc_kmer_to_wire.restype = None
+        L.orc_kmer_from_wire.argtypes = [C.c_void_p, C.POINTER(C.c_int32), u64p]
         _LIB = L
     return _LIB
 
@@ -220,3 +228,33 @@ def synth_words_repeat(seed, n_bases, motif_len):
     words = np.empty(max(num_words(n_bases), 1), dtype=np.uint64)
     lib().orc_synth_words_repeat(seed, n_bases, motif_len, _p(words))
     return words[:num_words(n_bases)]
+
+
+def dna_to_wire(words, n_bases):
+    """dna_send (dna.c:270-291) with a working int64 length: bytes"""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    buf = C.create_string_buffer(int(lib().orc_dna_wire_size(n_bases)))
+    lib().orc_dna_to_wire(_p(w), n_bases, buf)
+    return buf.raw
+
+
+def dna_from_wire(wire):
+    """dna_recv (dna.c:244-268): bytes -> (words, n_bases)"""
+    b = bytes(wire)
+    n = C.c_uint64()
+    _chk(lib().orc_dna_from_wire(b, len(b), C.byref(n), None))
+    w = np.zeros(num_words(n.value), dtype=np.uint64)
+    _chk(lib().orc_dna_from_wire(b, len(b), C.byref(n), _p(w)))
+    return w, n.value
+
+
+def kmer_to_wire(length, bits):
+    buf = C.create_string_buffer(12)
+    lib().orc_kmer_to_wire(length, bits, buf)
+    return buf.raw
+
+
+def kmer_from_wire(wire):
+    ln, bits = C.c_int32(), C.c_uint64()
+    _chk(lib().orc_kmer_from_wire(bytes(wire), C.byref(ln), C.byref(bits)))
+    return ln.value, bits.value

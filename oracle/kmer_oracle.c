@@ -517,3 +517,65 @@ void orc_synth_words_repeat(uint64_t seed, uint64_t n_bases, uint64_t motif_len,
         words[w] = v;
     }
 }
+
+/* ---- binary wire image: dna_send/dna_recv (dna.c:244-291), kmer_send/kmer_recv (dna.c:552-597) ---- */
+static void put_be64(unsigned char *p, uint64_t v)
+{
+    for (int i = 0; i < 8; i++)
+        p[i] = (unsigned char)(v >> (56 - 8 * i));          /* pq_sendint64: network byte order */
+}
+static uint64_t get_be64(const unsigned char *p)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++)
+        v = (v << 8) | p[i];
+    return v;
+}
+
+uint64_t orc_dna_wire_size(uint64_t n_bases) { return 8 + 8 * orc_dna_num_words(n_bases); }
+
+void orc_dna_to_wire(const uint64_t *words, uint64_t n_bases, unsigned char *wire)
+{
+    uint64_t bit_length = orc_dna_num_words(n_bases);        /* dna.c:279 */
+    put_be64(wire, n_bases);                                 /* dna.c:282 (as an int64) */
+    for (uint64_t i = 0; i < bit_length; i++)                /* dna.c:284-286 */
+        put_be64(wire + 8 + 8 * i, words[i]);
+}
+
+int orc_dna_from_wire(const unsigned char *wire, uint64_t wire_bytes, uint64_t *n_bases, uint64_t *words)
+{
+    if (wire_bytes < 8)
+        return ORC_ERR_NOMEM;
+    uint64_t length = get_be64(wire);                        /* dna.c:251 */
+    if (length == 0)
+        return ORC_ERR_DNA_EMPTY;                            /* the type has no empty value (dna.c:160-161) */
+    uint64_t bit_length = orc_dna_num_words(length);         /* dna.c:252-253 */
+    if (length > (uint64_t)1 << 40 || wire_bytes != 8 + 8 * bit_length)
+        return ORC_ERR_NOMEM;
+    *n_bases = length;
+    if (words) {
+        for (uint64_t i = 0; i < bit_length; i++)            /* dna.c:263-265 */
+            words[i] = get_be64(wire + 8 + 8 * i);
+        if (length % 32)                                     /* keep the palloc0 invariant: tail bits zero */
+            words[bit_length - 1] &= (((uint64_t)1 << (2 * (length % 32))) - 1);
+    }
+    return ORC_OK;
+}
+
+void orc_kmer_to_wire(int32_t length, uint64_t bits, unsigned char wire[12])
+{
+    uint32_t l = (uint32_t)length;                           /* dna.c:588: pq_sendint(.., sizeof(int)) */
+    wire[0] = (unsigned char)(l >> 24); wire[1] = (unsigned char)(l >> 16);
+    wire[2] = (unsigned char)(l >> 8);  wire[3] = (unsigned char)l;
+    put_be64(wire + 4, bits);                                /* dna.c:591 */
+}
+
+int orc_kmer_from_wire(const unsigned char wire[12], int32_t *length, uint64_t *bits)
+{
+    int32_t l = (int32_t)(((uint32_t)wire[0] << 24) | ((uint32_t)wire[1] << 16) | ((uint32_t)wire[2] << 8) | wire[3]);
+    if (l <= 0 || l > 32)
+        return ORC_ERR_KMER_TOO_LONG;                        /* dna.c:566-568 */
+    *length = l;
+    *bits = get_be64(wire + 4);                              /* dna.c:571 */
+    return ORC_OK;
+}

@@ -51,6 +51,19 @@ uint64_t orc_dna_num_words(uint64_t n_bases);
 int orc_dna_encode(const char *seq, uint64_t *words /* zeroed, orc_dna_num_words(strlen) */);
 void orc_dna_decode(const uint64_t *words, uint64_t n_bases, char *out /* n_bases+1 */);
 
+/* ---- binary wire image (dna_send / dna_recv, dna.c:244-291; kmer_send / kmer_recv, dna.c:552-597) ----
+ * What the reference means to put on the wire: the length, then every packed word, each through
+ * pq_sendint64 (network byte order).  Its length field goes through pq_sendint / pq_getmsgint with
+ * size 8, which PostgreSQL rejects at run time ("unsupported integer size 8"), so the reference's
+ * binary I/O never works; here the length is an int64 in network byte order like the words (dna)
+ * and an int32 (kmer: sizeof(int) = 4, which pq_sendint accepts).  No reference test covers it. */
+uint64_t orc_dna_wire_size(uint64_t n_bases);                       /* 8 + 8 * words */
+void orc_dna_to_wire(const uint64_t *words, uint64_t n_bases, unsigned char *wire);
+/* returns ORC_ERR_DNA_EMPTY for a zero length, ORC_ERR_NOMEM for a size mismatch; tail bits are cleared */
+int orc_dna_from_wire(const unsigned char *wire, uint64_t wire_bytes, uint64_t *n_bases, uint64_t *words /* may be NULL */);
+void orc_kmer_to_wire(int32_t length, uint64_t bits, unsigned char wire[12]);
+int orc_kmer_from_wire(const unsigned char wire[12], int32_t *length, uint64_t *bits);   /* dna.c:566-568 length check */
+
 /* ---- kmer type (dna.c:397-420, 428-452, 457-479, 487-515) ---- */
 int orc_kmer_encode(const char *seq, int32_t *length, uint64_t *bits);
 void orc_kmer_decode(uint64_t bits, int k, char *out /* k+1 */);

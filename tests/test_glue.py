@@ -28,6 +28,26 @@ def test_dna_io(g):
         assert str(ei.value) == msg                                          # dna.c:161,166
 
 
+def test_binary_io(g):
+    """dna_send/dna_recv, kmer_send/kmer_recv (dna.c:244-291, 552-597) against the oracle's wire image"""
+    import oracle as orc
+    seq = "ATCGTAGCGTACGTTAGCCATGGATCCAAGTTCGATCGGCTAACGTAGCTAGGATCCTTAAGGCCATGCAT"
+    for s_ in ("A", "ATCG", seq, seq[:32], seq[:33], seq * 7):
+        wire = g.dna(s_).send()
+        assert wire == orc.dna_to_wire(*orc.dna_encode(s_))
+        assert str(g.dna.recv(wire)) == s_
+    for bad, msg in ((b"", "insufficient data left in message"), (bytes(8), "DNA sequence cannot be empty"),
+                     (orc.dna_to_wire(*orc.dna_encode(seq))[:-8], "insufficient data left in message")):
+        with pytest.raises(g.GlueError) as ei:
+            g.dna.recv(bad)
+        assert str(ei.value) == msg
+    k = g.kmer("ATCGA")
+    assert k.send() == orc.kmer_to_wire(5, 0xE4) and g.kmer.recv(k.send()) == k
+    with pytest.raises(g.GlueError) as ei:
+        g.kmer.recv(orc.kmer_to_wire(33, 1))
+    assert str(ei.value) == "Invalid K-mer length: must be between 1 and 32"     # dna.c:567
+
+
 def test_kmer_io_and_eq(g):
     assert str(g.kmer("ACGTAC")) == "ACGTAC"
     assert g.kmer("ATCG") == g.kmer("ATCG") and g.kmer("ATCG") != g.kmer("GTCA")

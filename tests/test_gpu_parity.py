@@ -68,6 +68,34 @@ def test_pack_unpack_matches_oracle(ctx, n):
     d.free()
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 64, 65, 1000, 100_003, 2_000_017])
+def test_wire_image_matches_oracle(ctx, pkg, n):
+    """dna_send / dna_recv on the device (dna.c:244-291): byte for byte the oracle's wire image"""
+    words = orc.synth_words(777 + n, n)
+    wire = orc.dna_to_wire(words, n)
+    d = ctx.upload(words, n)
+    assert ctx.to_wire(d) == wire, f"to_wire n={n}"
+    d.free()
+    r = ctx.from_wire(wire)
+    assert r.n_bases == n
+    assert_same(r.download(), words, f"from_wire n={n}")
+    r.free()
+    if n % 32:                                  # bits behind the last base are cleared (dna.c:186)
+        dirty = bytearray(wire)
+        dirty[-8] |= 0xC0
+        r = ctx.from_wire(bytes(dirty))
+        assert_same(r.download(), words, f"from_wire dirty tail n={n}")
+        r.free()
+
+
+def test_wire_image_errors(ctx, pkg):
+    wire = orc.dna_to_wire(*orc.dna_encode("ATCGATCG"))
+    for bad, code in ((wire[:-1], 5), (wire + b"\0" * 8, 5), (b"\0" * 4, 5), (bytes(8), 11)):
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            ctx.from_wire(bad)
+        assert ei.value.code == code            # DNAGPU_ERR_BAD_ARG / DNAGPU_ERR_DNA_EMPTY
+
+
 def test_pack_errors_are_the_references(ctx, pkg):
     with pytest.raises(pkg.DnaGpuError) as ei:
         ctx.pack("")

@@ -188,3 +188,34 @@ def test_synth_tail_bits_zero_and_repeat():
     base = orc.dna_decode(orc.synth_words(9, n), n)
     assert s[: n // 2] == base[: n // 2]
     assert all(s[n // 2 + i] == base[i % motif] for i in range(n - n // 2))
+
+
+def test_wire_image_known_answers():
+    """dna_send/dna_recv, kmer_send/kmer_recv (dna.c:244-291, 552-597): length then packed words, each in
+    network byte order.  The reference holds no test or fixture for its binary I/O (and its length field
+    cannot work: pq_sendint with size 8), so these vectors are written out by hand from the format."""
+    w, n = orc.dna_encode("ATCG")                       # word 0xe4
+    wire = orc.dna_to_wire(w, n)
+    assert wire == bytes.fromhex("0000000000000004" "00000000000000e4")
+    w2, n2 = orc.dna_from_wire(wire)
+    assert n2 == 4 and list(w2) == [0xE4]
+    # the 71-base word-straddling vector of SURVEY.md 8(a)
+    seq = "ATCGTAGCGTACGTTAGCCATGGATCCAAGTTCGATCGGCTAACGTAGCTAGGATCCTTAAGGCCATGCAT"
+    w, n = orc.dna_encode(seq)
+    wire = orc.dna_to_wire(w, n)
+    assert wire == bytes.fromhex("0000000000000047" "5c293d2b1787b1e4" "bc1693c6c781be4e" "00000000000012d2")
+    w2, n2 = orc.dna_from_wire(wire)
+    assert n2 == 71 and np.array_equal(w2, w) and orc.dna_decode(w2, n2) == seq
+    # bits behind the last base are cleared on receive (palloc0 invariant, dna.c:186)
+    dirty = bytearray(wire)
+    dirty[-8] = 0xFF
+    w3, _ = orc.dna_from_wire(bytes(dirty))
+    assert np.array_equal(w3, w)
+    for bad in (b"", wire[:-1], wire + b"\0", bytes(8)):
+        with pytest.raises(orc.OracleError):
+            orc.dna_from_wire(bad)
+    assert orc.kmer_to_wire(5, 0xE4) == bytes.fromhex("00000005" "00000000000000e4")
+    assert orc.kmer_from_wire(bytes.fromhex("00000020" "5c293d2b1787b1e4")) == (32, 0x5C293D2B1787B1E4)
+    for bad_len in (0, 33, -1):
+        with pytest.raises(orc.OracleError):
+            orc.kmer_from_wire(orc.kmer_to_wire(bad_len, 1))
