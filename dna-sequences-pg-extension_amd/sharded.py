@@ -93,8 +93,11 @@ class GpuEngine:
 
     def chunk_tensor(self, dna, per_words):
         """the chunk as an int64 tensor of per_words words (zero padded) for the all-gather"""
-        t = torch.zeros(per_words, dtype=torch.int64, device=self.device)
         nw = (dna.n_bases + 31) // 32
+        if nw == per_words:                 # a full chunk: the library's buffer itself, no copy
+            self.ctx.synchronize()
+            return torch.as_tensor(_DevArray(dna.device_words, nw), device=self.device)
+        t = torch.zeros(per_words, dtype=torch.int64, device=self.device)
         if nw:
             src = torch.as_tensor(_DevArray(dna.device_words, nw), device=self.device)
             self.ctx.synchronize()
@@ -139,9 +142,10 @@ class GpuEngine:
         dna.free()
 
 
-def gather_sequence(chunk_t, world, engine):
-    """All-gather of the packed chunks -> the whole packed sequence on every rank."""
-    if world == 1:
+def gather_sequence(chunk_t, world, engine, always=False):
+    """All-gather of the packed chunks -> the whole packed sequence on every rank.
+    always: run the collective at world size 1 too (the RCCL smoke test on a one-GPU box)."""
+    if world == 1 and not always:
         return chunk_t
     via_host = dist.get_backend() == "gloo" and chunk_t.is_cuda     # gloo has no device all-gather
     if via_host:
@@ -155,23 +159,23 @@ def gather_sequence(chunk_t, world, engine):
     return full
 
 
-def count_sharded(engine, seed, n_bases, k, rank, world, chunk=None):
+def count_sharded(engine, seed, n_bases, k, rank, world, chunk=None, always_collective=False):
     """One full sharded count (all-gather of the packed sequence + owner-filtered count).
     Returns (hist, chunk): this rank's part of the global histogram and its resident chunk."""
     per, chunks = word_chunks(n_bases, world)
     if chunk is None:
         chunk = engine.make_chunk(seed, *chunks[rank])
     chunk_t = engine.chunk_tensor(chunk, per)
-    full = gather_sequence(chunk_t, world, engine)
+    full = gather_sequence(chunk_t, world, engine, always_collective)
     hist = engine.count_owned(full, n_bases, k, rank, world)
     return hist, chunk
 
 
-def exchange(send, offsets, world, engine):
+def exchange(send, offsets, world, engine, always=False):
     """All-to-all of the owner groups.  send: int64 tensor grouped by owner; offsets[o]..offsets[o+1]
     is owner o's group.  Returns the keys this rank owns (unordered)."""
     in_splits = [offsets[o + 1] - offsets[o] for o in range(world)]
-    if world == 1:
+    if world == 1 and not always:
         return send
     via_host = dist.get_backend() == "gloo" and send.is_cuda
     sizes = torch.tensor(in_splits, dtype=torch.int64, device="cpu" if via_host else send.device)
@@ -189,13 +193,13 @@ def exchange(send, offsets, world, engine):
     return recv
 
 
-def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None):
+def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False):
     """The key-exchange variant.  Returns (hist, dna) like count_sharded."""
     first, n_mine, base_lo, base_hi = shard_ranges(n_bases, k, world)[rank]
     if dna is None:
         dna = engine.make_shard(seed, base_lo, base_hi)
     send, offsets = engine.partition(dna, k, n_mine, world)
-    recv = exchange(send, offsets, world, engine)
+    recv = exchange(send, offsets, world, engine, always_collective)
     key_min, key_max = owner_key_range(k, rank, world)
     hist = engine.count_keys(recv, k, key_min, key_max)
     engine.release()

@@ -87,7 +87,12 @@ def main():
     engine_name, n_bases, k, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "gather"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("SHARD_BACKEND", "gloo")     # "nccl" = RCCL: the product backend (GPU tests)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_package()
     sh = importlib.import_module(pkg.__name__ + ".sharded")
     seed = 0xD2A0003
@@ -98,9 +103,9 @@ def main():
     else:
         engine = OracleEngine()
     if mode == "gather":
-        hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world)
+        hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world, always_collective=True)
     else:
-        hist, dna = sh.count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world)
+        hist, dna = sh.count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, always_collective=True)
     keys, counts = hist.download()
     parts = [None] * world
     dist.all_gather_object(parts, (np.asarray(keys), np.asarray(counts)))

@@ -11,12 +11,12 @@ import pytest
 from __graft_entry__ import ROOT, load_package
 
 
-def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather"):
-    out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}.json"
+def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather", backend="gloo"):
+    out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}_{backend}.json"
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SHARD_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"),
                                        engine, str(n_bases), str(k), str(out), mode], env=env))
     for p in procs:
@@ -66,4 +66,14 @@ def test_sharded_count_gloo_gpu_engine(tmp_path, world, n_bases, k, mode):
     if mode == "keys" and k < 6:
         pytest.skip("the key-exchange variant needs 2k > 10 bits")
     res = run_world("gpu", world, n_bases, k, tmp_path, 29531 + world + (10 if mode == "keys" else 0), mode)
+    assert res["ok"] and res["sorted"], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["gather", "keys"])
+def test_sharded_count_rccl_one_rank(tmp_path, mode):
+    """The product backend (nccl = RCCL) with the collectives forced at world size 1: device tensors, the
+    library's stream and torch's stream meet the way they do on the 8-GPU node (a one-GPU box cannot
+    host two RCCL ranks)."""
+    res = run_world("gpu", 1, 2_000_000, 31, tmp_path, 29561 + (1 if mode == "keys" else 0), mode, backend="nccl")
     assert res["ok"] and res["sorted"], res
