@@ -1264,6 +1264,13 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         const bool has_next = ln < n_leaves;
         const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
         __syncthreads();                           // A/H of the previous leaf are dead
+        // Every path through an iteration "uses" the prefetched keys here.  Without this a leaf that
+        // never reads them (a single-key leaf) leaves loads in flight, and the compiler guards the
+        // next prefetch into the same registers with s_waitcnt vmcnt(0) -- on every path, which
+        // also waits for the placement atomic issued just before it.
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++)
+            asm volatile("" : "+v"(key[j]));
         STAMP(0);  // waited for the previous leaf / descriptor
         const u32 len = nd.len;
         const int rem = (int)(nd.meta & 0xff);
@@ -1388,19 +1395,17 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             }
         }
 
-        // ---- the sort no longer needs key[]: start the next leaf's loads (they land while this
-        // leaf's heads, placement and output run).  Wave 0 issues its share only after the
-        // placement atomic below: a wave's vector-memory operations complete in order, so an atomic
-        // issued behind eight HBM loads would wait for all of them.
+        // ---- the sort no longer needs key[]: the next leaf's loads are issued below, behind wave
+        // 0's placement atomic (a wave's vector-memory operations retire in order: an atomic issued
+        // behind the HBM loads would wait for all of them), from ONE code site for every wave (with a
+        // second site for wave 0 the compiler's wait-count pass guards the key registers of the
+        // other site with a vmcnt(0), i.e. waits for the atomic on the spot).  The loads are
+        // unconditional (no next leaf: one harmless word of the leaf list itself), so the number of
+        // operations behind the atomic is fixed and its result can be awaited with a count.
         const bool next_loads = has_next && nn.len > 0 && (nn.meta & 0xff) != 0 && !(nn.meta & NODE_TERMINAL);
-        const u64 *__restrict__ nsrc = ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start;
-        if (next_loads && wave != 0) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                u32 i = tid + j * NT;
-                key[j] = NT_LOAD(&nsrc[i < nn.len ? i : nn.len - 1]);
-            }
-        }
+        const u64 *__restrict__ nsrc = next_loads ? ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start
+                                                  : reinterpret_cast<const u64 *>(leaves);
+        const u32 nlim = next_loads ? nn.len : 1u;
 
         u64 ob_reg = 0;                            // wave 0, lane 63: the leaf's output base
         if (sorted_path) {
@@ -1434,20 +1439,31 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 D = 1;
             }
             // ---- placement: one atomic per leaf, issued as early as D is known; its result is
-            // only needed at the last barrier before the output
+            // only needed at the last barrier before the output.  The add is written in assembly so
+            // that nothing waits for its result here: left to the compiler, a wave-uniform atomic
+            // goes through its atomic optimizer (one lane adds, s_waitcnt vmcnt(0), readfirstlane),
+            // and a plain one still got a vmcnt(0) from register reuse.  The result is awaited below
+            // with s_waitcnt vmcnt(ITEMS): exactly the ITEMS loads of the next leaf are behind it.
             if (lane == 63) {
                 sh_D = D;
-                if (D > 0)
-                    ob_reg = (dbg & 2) ? (u64)nd.start : (u64)atomicAdd(cursor, (unsigned long long)D);
-            }
-            __builtin_amdgcn_sched_barrier(0);     // (keep the atomic ahead of this wave's loads)
-            if (next_loads) {
-#pragma unroll
-                for (int j = 0; j < ITEMS; j++) {
-                    u32 i = tid + j * NT;
-                    key[j] = NT_LOAD(&nsrc[i < nn.len ? i : nn.len - 1]);
+                if (D > 0) {
+                    if (dbg & 2) {
+                        ob_reg = (u64)nd.start;
+                    } else {
+                        const unsigned long long dd = D;
+                        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0"
+                                     : "=&v"(ob_reg)
+                                     : "v"(cursor), "v"(dd)
+                                     : "memory");
+                    }
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);         // (keep the atomic ahead of wave 0's loads)
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            u32 i = tid + j * NT;
+            key[j] = NT_LOAD(&nsrc[i < nlim ? i : nlim - 1]);
         }
         if (sorted_path) {
             __syncthreads();
@@ -1466,6 +1482,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             // (H as bin offsets is dead: every read of it happened before the barriers above)
         }
         if (wave == 0 && lane == 63) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ob_reg) : "n"(ITEMS) : "memory");
             sh_obase = ob_reg;
             seg_off[li] = ob_reg;
             seg_cnt[li] = D;
