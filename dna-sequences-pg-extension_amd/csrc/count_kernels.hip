@@ -365,7 +365,7 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
     } else {
         const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + origin;
         for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS)
-            atomicAdd(&h[(u32)(src[i] >> shift) & dmask], 1u);
+            atomicAdd(&h[(u32)(NT_LOAD(&src[i]) >> shift) & dmask], 1u);
     }
     __syncthreads();
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;

@@ -53,6 +53,7 @@ hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 moti
 // One workgroup = 4096 consecutive rows; lane l of each wave-instruction stores rows 2l, 2l+1 of
 // a 128-row group as one 16-byte store: 1 KiB contiguous per wave-instruction.
 constexpr int EXTRACT_TILE = 4096;
+typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void extract_kernel(const u64 *__restrict__ words, u64 n_words, u64 first,
                                                       u64 count, u64 mask, u64 *__restrict__ out)
@@ -68,16 +69,16 @@ __global__ __launch_bounds__(256) void extract_kernel(const u64 *__restrict__ wo
         if (i + 1 < count) {
             u64 k1 = key_at(words, n_words, first + i + 1, mask);
             if (aligned) {
-                ulonglong2 v;
+                ull2_t v;
                 v.x = k0;
                 v.y = k1;
-                *reinterpret_cast<ulonglong2 *>(out + i) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<ull2_t *>(out + i));
             } else {
-                out[i] = k0;
-                out[i + 1] = k1;
+                __builtin_nontemporal_store(k0, &out[i]);
+                __builtin_nontemporal_store(k1, &out[i + 1]);
             }
         } else {
-            out[i] = k0;
+            __builtin_nontemporal_store(k0, &out[i]);
         }
     }
 }
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(256) void filter_write_kernel(const u64 *__restrict
             u64 idx = tile_off + cnt[j * 4 + wave] + (u64)__popcll(ballots[j] & below);
             if (idx < cap) {
                 if (out_keys)
-                    out_keys[idx] = keys[j];
+                    __builtin_nontemporal_store(keys[j], &out_keys[idx]);
                 if (out_pos)
-                    out_pos[idx] = first + base + (u64)j * 256 + threadIdx.x;
+                    __builtin_nontemporal_store((u64)(first + base + (u64)j * 256 + threadIdx.x), &out_pos[idx]);
             }
         }
     }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void hash_batch_kernel(const u64 *__restrict__
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 stride = (u64)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
-        out[i] = pg_kmer_hash(keys[i]);
+        __builtin_nontemporal_store(pg_kmer_hash(__builtin_nontemporal_load(&keys[i])), &out[i]);
 }
 
 hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s)
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void match_batch_kernel(const u64 *__restrict_
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 stride = (u64)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
-        flags[i] = filter_match(f, keys[i]) ? 1 : 0;
+        flags[i] = filter_match(f, __builtin_nontemporal_load(&keys[i])) ? 1 : 0;
 }
 
 hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_t *flags, hipStream_t s)
@@ -392,13 +393,13 @@ __global__ __launch_bounds__(256) void wire_swap_kernel(const u64 *__restrict__ 
     const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n_words)
         return;
-    u64 a = __builtin_bswap64(src[i]);
+    u64 a = __builtin_bswap64(__builtin_nontemporal_load(&src[i]));
     if (i + 1 < n_words) {
-        u64 b = __builtin_bswap64(src[i + 1]);
+        u64 b = __builtin_bswap64(__builtin_nontemporal_load(&src[i + 1]));
         if (i + 2 == n_words)
             b &= last_mask;
-        dst[i] = a;
-        dst[i + 1] = b;
+        __builtin_nontemporal_store(a, &dst[i]);
+        __builtin_nontemporal_store(b, &dst[i + 1]);
     } else {
         dst[i] = a & last_mask;
     }
