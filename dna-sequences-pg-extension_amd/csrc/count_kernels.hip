@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         if (level == 0) {
             if (want > MAX_SPLIT_BITS)
                 want = (want + 1) / 2;          // two balanced levels
-        } else if (level >= 2) {
-            want += 4;                          // an oversize survivor is skewed: fan out harder
-        }
+        } else if (level >= 2 && nd.len > 4u * (u32)LEAF_CAP) {
+            want += 4;                          // a far oversize survivor is skewed: fan out harder
+        }                                       // (a leaf just over the capacity is halved)
         bits = want;
         if (bits > MAX_SPLIT_BITS) bits = MAX_SPLIT_BITS;
         if (level >= 1 && bits > l1_cap) bits = l1_cap;
@@ -797,17 +797,20 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
         // place: a returning add on the digit's cursor is the staged slot.  All the adds first, then
         // all the stores: written as one loop, every store waited for its own add's round trip.
         u32 slot[WC_ITEMS];
+        u64 kvs[SRC_DNA ? WC_ITEMS : 1];            // dna root: the extracted windows are kept for the stores
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
             u32 i = SRC_DNA ? ((u32)j < per ? tid * per + j : tn) : tid + j * NTH;
             u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
+            if (SRC_DNA)
+                kvs[SRC_DNA ? j : 0] = kv;
             slot[j] = ~0u;
             if (i < tn)
                 slot[j] = atomicAdd(&curs[(u32)(kv >> shift) & dmask], 1u);
         }
 #pragma unroll
         for (int j = 0; j < WC_ITEMS; j++) {
-            u64 kv = SRC_DNA ? win16_key(w, j, mask) : key[SRC_DNA ? 0 : j];
+            u64 kv = SRC_DNA ? kvs[SRC_DNA ? j : 0] : key[SRC_DNA ? 0 : j];
             if (slot[j] != ~0u)
                 stage[slot[j]] = kv;
         }

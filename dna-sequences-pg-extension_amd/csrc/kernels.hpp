@@ -45,7 +45,7 @@ hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total,
 // next most significant bits; leaves (<= LEAF_CAP keys, or no bits left) are sorted and run-length
 // encoded in LDS, in key order, with a chained scan giving each leaf its output offset.
 constexpr int LEAF_CAP = 4096;        // max keys a leaf workgroup sorts in LDS
-constexpr int LEAF_TARGET = 3400;     // planned leaf size: a split aims at means in (1700, 3400] (random leaves spread a few %)
+constexpr int LEAF_TARGET = 3850;     // planned leaf size: a split aims at means in (1925, 3850]; a leaf that still exceeds LEAF_CAP is halved by one more level
 constexpr int MAX_SPLIT_BITS = 10;    // widest digit of one level (1024 children)
 constexpr int ROW_STRIDE = 1 << MAX_SPLIT_BITS;
 
