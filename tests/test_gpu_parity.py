@@ -580,3 +580,41 @@ def test_config3_k31_chr1_scale_properties(ctx):
         assert i < len(gk) and gk[i] == key
     h.free()
     d.free()
+
+
+def test_config4_k31_3G_properties(ctx):
+    """configs[3] at its full size on one GPU: k=31 over 3 Gbase, seed 0xD2A0003 (the bench workload).
+    Size-independent properties: sum(count) = number of rows; groups strictly ascending inside and
+    across download windows; the eight owners' histograms (the sharded path) are disjoint and their
+    digests add up to the single-GPU digest (a checksum of checksums); rows owned add up to all rows."""
+    n, k, seed = 3_000_000_000, 31, 0xD2A0003
+    d = ctx.synth(seed, n)
+    h = ctx.count_kmers(d, k)
+    total, distinct, unique, checksum = h.summary()
+    assert total == n - k + 1
+    assert total - 100 < distinct <= total and unique <= distinct
+    prev_last = None
+    for first in (0, distinct // 3, distinct - 4_000_000):
+        gk, gc = h.download(first, 4_000_000)
+        assert np.all(gk[1:] > gk[:-1]), f"window at {first}: keys not strictly ascending"
+        assert gc.min() >= 1
+        if prev_last is not None:
+            assert gk[0] > prev_last
+        prev_last = int(gk[-1])
+    h.free()
+    M = (1 << 64) - 1
+    t_sum = d_sum = u_sum = c_sum = 0
+    last_key = -1
+    for owner in range(8):
+        ho = ctx.count_kmers_owned(d, k, owner, 8)
+        t, dd, u, c = ho.summary()
+        assert ho.total == t
+        fk, _ = ho.download(0, 1)
+        lk, _ = ho.download(dd - 1, 1)
+        assert int(fk[0]) > last_key, "owners' key ranges overlap or are out of order"
+        last_key = int(lk[0])
+        t_sum, d_sum, u_sum, c_sum = t_sum + t, d_sum + dd, u_sum + u, (c_sum + c) & M
+        ho.free()
+    assert (t_sum, d_sum, u_sum, c_sum) == (total, distinct, unique, checksum)
+    d.free()
+    ctx.trim()
