@@ -185,6 +185,8 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         if (bits > rem) bits = rem;
         if (bits < 1) bits = 1;
     }
+    if (bits == 0 && rem > 0 && !(nd.meta & NODE_TERMINAL) && nd.len > (u32)LEAF_CAP_SMALL)
+        atomicAdd(&ctr->n_big, 1u);
     nodes[i].split = (u32)bits;
     outc[i] = bits ? (1u << bits) : 1u;
     nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
@@ -1178,27 +1180,37 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const u32 *H, const u
             }
         }
     }
-    u32 more = 0;                                   // bit j: row j's bin has more than four members
+    u32 more = 0;                                   // bit j: row j's bin has more than eight members
+    u32 any5 = 0;                                   // some row of this thread has more than four
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
-        const u32 i = tid + j * NT < len ? tid + j * NT : len - 1;
-        T o[4];
-        u32 idx[4];
+        pos[j] = lo[j];
+        any5 |= size[j] > 4 ? 1u : 0u;
+        more |= size[j] > 8 ? (1u << j) : 0u;
+    }
+    const int tiers = __any(any5 != 0) ? 2 : 1;     // members 0-3 of every bin, then -- if any lane of the
+#pragma unroll 1                                    // wave needs them -- members 4-7, again as one batch
+    for (int g = 0; g < tiers; g++) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            idx[t] = (u32)t < size[j] ? lo[j] + t : i;
-            o[t] = *reinterpret_cast<const T *>(&A[idx[t]]);     // (little endian: low dword first)
-        }
-        u32 cnt = 0;
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 i = tid + j * NT < len ? tid + j * NT : len - 1;
+            T o[4];
+            u32 idx[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (sizeof(T) == 4)
-                cnt += (((u64)o[t] << 32) | idx[t]) < (((u64)(u32)key[j] << 32) | i) ? 1u : 0u;
-            else
-                cnt += ((u64)o[t] < key[j] || ((u64)o[t] == key[j] && idx[t] < i)) ? 1u : 0u;
+            for (int t = 0; t < 4; t++) {
+                idx[t] = (u32)(4 * g + t) < size[j] ? lo[j] + 4 * g + t : i;
+                o[t] = *reinterpret_cast<const T *>(&A[idx[t]]);     // (little endian: low dword first)
+            }
+            u32 cnt = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (sizeof(T) == 4)
+                    cnt += (((u64)o[t] << 32) | idx[t]) < (((u64)(u32)key[j] << 32) | i) ? 1u : 0u;
+                else
+                    cnt += ((u64)o[t] < key[j] || ((u64)o[t] == key[j] && idx[t] < i)) ? 1u : 0u;
+            }
+            pos[j] += cnt;
         }
-        pos[j] = lo[j] + cnt;
-        more |= size[j] > 4 ? (1u << j) : 0u;
     }
     if (more) {
 #pragma unroll
@@ -1207,7 +1219,7 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const u32 *H, const u
                 const u32 i = tid + j * NT < len ? tid + j * NT : len - 1;
                 u32 cnt = 0;
 #pragma unroll 1
-                for (u32 m = lo[j] + 4; m < lo[j] + size[j]; m++) {
+                for (u32 m = lo[j] + 8; m < lo[j] + size[j]; m++) {
                     const u64 o = A[m];
                     cnt += (o < key[j]) || (o == key[j] && m < i);
                 }
@@ -1217,7 +1229,41 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const u32 *H, const u
     }
 }
 
-template <int NT, int MINW>
+// A leaf that sorts (not a single-key node) belongs to the class of the kernel whose capacity it needs.
+__device__ __forceinline__ bool leaf_in_class(const Node &nd, bool big_class)
+{
+    const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
+    return (sorts && nd.len > (u32)LEAF_CAP_SMALL) == big_class;
+}
+
+// The first leaf of the class at or behind `from`, in steps of `step` (n_leaves if none): the 64 lanes
+// test 64 candidates per round (a scalar walk paid one memory latency per skipped leaf).
+__device__ __forceinline__ u32 next_leaf_in_class(const Node *__restrict__ leaves, u32 n_leaves, u32 from, u32 step,
+                                                  bool big_class)
+{
+    const u32 lane = threadIdx.x & 63;
+    for (u64 base = from; base < n_leaves; base += (u64)64 * step) {
+        const u64 cand = base + (u64)lane * step;
+        bool ok = false;
+        if (cand < n_leaves) {
+            Node nd;
+            nd.len = leaves[cand].len;
+            nd.meta = leaves[cand].meta;
+            ok = leaf_in_class(nd, big_class);
+        }
+        const u64 m = __ballot(ok);
+        if (m)
+            return (u32)(base + (u64)__builtin_ctzll(m) * step);
+    }
+    return n_leaves;
+}
+
+// CAP = 4096 (four keys per thread at 1024 threads) or 6144 (six): the host launches one kernel per
+// class present; each skips the other class's leaves.  Bigger leaves let the level above split on
+// half as many digits (15 % cheaper per key), smaller ones cost less per key here.
+// MIXED: the leaf list holds both classes and this kernel skips the other one's leaves (the search
+// loop costs registers, so launches over a single-class list use the MIXED = false instantiation).
+template <int NT, int MINW, int CAP, bool MIXED>
 __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                           const u64 *__restrict__ buf0,
                                                           const u64 *__restrict__ buf1,
@@ -1226,18 +1272,20 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                                                           u64 *__restrict__ out_keys,
                                                           u32 *__restrict__ out_counts, int dbg)
 {
-    constexpr int ITEMS = LEAF_CAP / NT;       // keys per thread
-    constexpr int BINS = LEAF_CAP;             // counting-sort bins (mean occupancy 0.35-0.7)
+    constexpr bool BIG = CAP > LEAF_CAP_SMALL;
+    constexpr int ITEMS = CAP / NT;            // keys per thread
+    constexpr int BINS = 4096;                 // counting-sort bins (mean occupancy 0.5-1.4)
     constexpr int BPT = BINS / NT;             // consecutive bins per thread in the scan (4 or 8)
     constexpr int SB = 12;
     constexpr int WAVES = NT / 64;
+    constexpr int ROWS = ITEMS * WAVES;        // 64-position rows of the staged leaf
     constexpr u32 BIG_BIN = 24;
-    static_assert(ITEMS * WAVES == 64, "row/wave table must have 64 entries");
+    static_assert(ROWS * 64 == CAP && ROWS <= 128, "one wave scans the rows' head counts, two per lane");
     static_assert((1 << SB) == BINS && BPT % 4 == 0, "bins");
 
-    __shared__ __attribute__((aligned(16))) u64 A[LEAF_CAP];
-    __shared__ __attribute__((aligned(16))) u32 H[LEAF_CAP + 8];   // bins -> offsets; later head positions
-    __shared__ u32 rowcnt[64];                 // [row][wave] head counts -> exclusive offsets
+    __shared__ __attribute__((aligned(16))) u64 A[CAP];
+    __shared__ __attribute__((aligned(16))) u32 H[CAP + 8];   // bins -> offsets; later head positions
+    __shared__ u32 rowcnt[ROWS];               // [row][wave] head counts -> exclusive offsets
     __shared__ u32 wtmp[WAVES];
     __shared__ u32 sh_D;
     __shared__ u64 sh_obase;
@@ -1248,6 +1296,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 li = blockIdx.x;
+    if (MIXED)
+        li = next_leaf_in_class(leaves, n_leaves, li, gridDim.x, BIG);
     if (li >= n_leaves)
         return;
     Node nd = leaves[li];
@@ -1263,7 +1313,9 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 
     STAMP_DECL
     for (;;) {
-        const u32 ln = li + gridDim.x;
+        u32 ln = li + gridDim.x;
+        if (MIXED)
+            ln = next_leaf_in_class(leaves, n_leaves, ln < n_leaves ? ln : n_leaves, gridDim.x, BIG);
         const bool has_next = ln < n_leaves;
         const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
         __syncthreads();                           // A/H of the previous leaf are dead
@@ -1434,10 +1486,16 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         }
         if (wave == 0) {
             if (sorted_path) {
-                const u32 v = rowcnt[lane];
-                const u32 inc = wave_incl_scan(v);
-                rowcnt[lane] = inc - v;
-                D = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+                const u32 v0 = lane < ROWS ? rowcnt[lane] : 0u;
+                const u32 v1 = lane + 64 < ROWS ? rowcnt[lane + 64] : 0u;
+                const u32 inc0 = wave_incl_scan(v0);
+                const u32 tot0 = (u32)__builtin_amdgcn_readlane((int)inc0, 63);
+                const u32 inc1 = wave_incl_scan(v1) + tot0;
+                if (lane < ROWS)
+                    rowcnt[lane] = inc0 - v0;
+                if (lane + 64 < ROWS)
+                    rowcnt[lane + 64] = inc1 - v1;
+                D = (u32)__builtin_amdgcn_readlane((int)inc1, 63);
             } else if (single) {
                 D = 1;
             }
@@ -1532,7 +1590,7 @@ static u32 leaves_grid(u32 n_leaves, int per_cu)
     return n_leaves < g ? n_leaves : g;
 }
 
-hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
 {
     if (n_leaves == 0)
@@ -1549,18 +1607,29 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, cons
             mult = 1;
     }
     unsigned long long *cur = reinterpret_cast<unsigned long long *>(cursor);
-    if (variant == 1)
-        hipLaunchKernelGGL((leaves_kernel<512, 6>), dim3(leaves_grid(n_leaves, 3 * mult)), dim3(512), 0, s, leaves,
-                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
-    else if (variant == 2)
-        hipLaunchKernelGGL((leaves_kernel<1024, 4>), dim3(leaves_grid(n_leaves, 1 * mult)), dim3(1024), 0, s, leaves,
-                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
-    else if (variant == 3)
-        hipLaunchKernelGGL((leaves_kernel<512, 4>), dim3(leaves_grid(n_leaves, 2 * mult)), dim3(512), 0, s, leaves,
-                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
-    else
-        hipLaunchKernelGGL((leaves_kernel<1024, 8>), dim3(leaves_grid(n_leaves, 2 * mult)), dim3(1024), 0, s, leaves,
-                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, dbg);
+    const bool mixed = n_big > 0 && n_big < n_leaves;
+#define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_)                                                                        \
+    do {                                                                                                              \
+        if (mixed)                                                                                                    \
+            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),   \
+                               dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
+                               out_counts, dbg);                                                                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, false>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),  \
+                               dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
+                               out_counts, dbg);                                                                      \
+    } while (0)
+    if (n_big < n_leaves) {                              // leaves of at most LEAF_CAP_SMALL keys (and single-key nodes)
+        if (variant == 2)
+            LAUNCH_LEAVES(1024, 4, LEAF_CAP_SMALL, 1);
+        else if (variant == 3)
+            LAUNCH_LEAVES(512, 4, LEAF_CAP_SMALL, 2);
+        else
+            LAUNCH_LEAVES(1024, 8, LEAF_CAP_SMALL, 2);
+    }
+    if (n_big > 0)                                       // leaves of up to LEAF_CAP keys
+        LAUNCH_LEAVES(1024, 8, LEAF_CAP, 2);
+#undef LAUNCH_LEAVES
 #ifdef DNAGPU_STAMPS
     stamps_report("leaves", 0, s);
 #endif

@@ -890,6 +890,7 @@ static const char *const LEVEL_PLAN_NAMES[] = {"level0_plan", "level1_plan", "le
 struct TreeResult {
     Node *nodes;      // final node list (leaves, or the children of a forced level)
     u32 n_nodes;
+    u32 n_big;        // leaves of more than LEAF_CAP_SMALL keys among them
     u64 n_keys;       // keys in the tree (== n unless an owner filter dropped some at the dna root)
     u64 *buf0;
     u64 *buf1;        // may be null if never needed
@@ -925,7 +926,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     RC_TRY(ps.alloc(1, &cur));
     HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
-    u32 n_nodes = 1;
+    u32 n_nodes = 1, n_big = 0;
 
     static u64 chunk_target = 0;                 // chunks per level (work units of the hist/scatter kernels)
     if (chunk_target == 0) {
@@ -955,6 +956,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (hc.n_split == 0) {
+            n_big = hc.n_big;                    // every node of the final list was planned (and counted) here
             ps.free_now(outc);
             ps.free_now(nch);
             ps.free_now(scan_tmp);
@@ -1010,6 +1012,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     }
     res->nodes = cur;
     res->n_nodes = n_nodes;
+    res->n_big = n_big;
     res->n_keys = n_keys;
     res->buf0 = buf0;
     res->buf1 = buf1;
@@ -1071,7 +1074,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             prof_mark(ctx, "leaves");
             e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
-                e = launch_leaves(tr.nodes, tr.n_nodes, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt, ok, oc,
+                e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt, ok, oc,
                                   ctx->stream);
             prof_mark(ctx, "end");
             if (e == hipSuccess)

@@ -44,8 +44,9 @@ hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total,
 // MSD radix tree over the keys (DESIGN.md "count"): every level splits the oversize nodes on their
 // next most significant bits; leaves (<= LEAF_CAP keys, or no bits left) are sorted and run-length
 // encoded in LDS, in key order, with a chained scan giving each leaf its output offset.
-constexpr int LEAF_CAP = 4096;        // max keys a leaf workgroup sorts in LDS
-constexpr int LEAF_TARGET = 3850;     // planned leaf size: a split aims at means in (1925, 3850]; a leaf that still exceeds LEAF_CAP is halved by one more level
+constexpr int LEAF_CAP = 6144;        // max keys a leaf workgroup sorts in LDS (48 KB of keys, six per thread)
+constexpr int LEAF_CAP_SMALL = 4096;  // leaves up to here take the four-keys-per-thread kernel
+constexpr int LEAF_TARGET = 5800;     // planned leaf size: a split aims at means in (2900, 5800]; a leaf that still exceeds LEAF_CAP is halved by one more level
 constexpr int MAX_SPLIT_BITS = 10;    // widest digit of one level (1024 children)
 constexpr int ROW_STRIDE = 1 << MAX_SPLIT_BITS;
 
@@ -73,6 +74,7 @@ struct LevelCounters {  // read back by the host once per level
     u32 n_chunks;
     u32 n_split;        // nodes being split this level
     u32 n_scatter;      // of which non-terminal (their keys move)
+    u32 n_big;          // unsplit nodes that sort more than LEAF_CAP_SMALL keys (the six-keys-per-thread leaves kernel)
 };
 
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
@@ -97,7 +99,7 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
                                 const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s);
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
-hipError_t launch_leaves(const Node *leaves, u32 n_leaves, const u64 *buf0, const u64 *buf1,
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
 // groups [first, first+count) of the ascending-key view -> dst arrays
 hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
