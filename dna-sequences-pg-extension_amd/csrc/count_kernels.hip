@@ -1455,8 +1455,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         // behind the HBM loads would wait for all of them), from ONE code site for every wave (with a
         // second site for wave 0 the compiler's wait-count pass guards the key registers of the
         // other site with a vmcnt(0), i.e. waits for the atomic on the spot).  The loads are
-        // unconditional (no next leaf: one harmless word of the leaf list itself), so the number of
-        // operations behind the atomic is fixed and its result can be awaited with a count.
+        // unconditional (no next leaf: one harmless word of the leaf list itself): one straight-line
+        // site, no branch for the wait-count pass to merge over.
         const bool next_loads = has_next && nn.len > 0 && (nn.meta & 0xff) != 0 && !(nn.meta & NODE_TERMINAL);
         const u64 *__restrict__ nsrc = next_loads ? ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start
                                                   : reinterpret_cast<const u64 *>(leaves);
@@ -1503,8 +1503,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             // only needed at the last barrier before the output.  The add is written in assembly so
             // that nothing waits for its result here: left to the compiler, a wave-uniform atomic
             // goes through its atomic optimizer (one lane adds, s_waitcnt vmcnt(0), readfirstlane),
-            // and a plain one still got a vmcnt(0) from register reuse.  The result is awaited below
-            // with s_waitcnt vmcnt(ITEMS): exactly the ITEMS loads of the next leaf are behind it.
+            // and a plain one still got a vmcnt(0) from register reuse.  The result is awaited just
+            // before the last barrier, one phase later.
             if (lane == 63) {
                 sh_D = D;
                 if (D > 0) {
@@ -1543,7 +1543,9 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             // (H as bin offsets is dead: every read of it happened before the barriers above)
         }
         if (wave == 0 && lane == 63) {
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ob_reg) : "n"(ITEMS) : "memory");
+            // (vmcnt(0), not a count of the loads issued behind the atomic: a register-spill reload
+            // the compiler may place in between would make a counted wait return too early)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ob_reg) : : "memory");
             sh_obase = ob_reg;
             seg_off[li] = ob_reg;
             seg_cnt[li] = D;
