@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
     outc[i] = bits ? (1u << bits) : 1u;
     nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
     if (bits) {
+        atomicMax(&ctr->max_bits, (u32)bits);
         atomicAdd(&ctr->n_split, 1u);
         if (bits < rem)
             atomicAdd(&ctr->n_scatter, 1u);
@@ -1057,7 +1058,8 @@ static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, con
 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
-                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s)
+                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 max_bits,
+                                hipStream_t s)
 {
     if (n_chunks == 0)
         return hipSuccess;
@@ -1101,7 +1103,8 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
             hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);
-        else if (nth_keys == 16)                  // experiment: 128-byte flush units
+        else if (nth_keys == 16 || (nth_keys == 1024 && max_bits <= 9))   // at most 512 digits: the carry of 128-byte flush units fits
+                                                  // (the dna root, write only, measured slower with them: 3.0 vs 2.65 ms at 1 Gbase)
             hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>), dim3(n_chunks), dim3(WC_THREADS),
                                wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
                                buf1, hist, tot, wdbg);

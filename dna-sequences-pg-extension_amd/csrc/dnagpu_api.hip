@@ -994,7 +994,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
             prof_mark(ctx, LEVEL_SCATTER_NAMES[li]);
             HIP_TRY(launch_level_scatter(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                          dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot,
-                                         src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, st));
+                                         src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, hc.max_bits, st));
         }
         ps.free_now(outc);
         ps.free_now(nch);

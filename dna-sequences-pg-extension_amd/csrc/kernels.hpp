@@ -74,6 +74,7 @@ struct LevelCounters {  // read back by the host once per level
     u32 n_chunks;
     u32 n_split;        // nodes being split this level
     u32 n_scatter;      // of which non-terminal (their keys move)
+    u32 max_bits;       // widest split of this level
     u32 n_big;          // unsplit nodes that sort more than LEAF_CAP_SMALL keys (the six-keys-per-thread leaves kernel)
 };
 
@@ -96,7 +97,8 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
 hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *tot, Node *next, hipStream_t s);
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
-                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s);
+                                const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 max_bits,
+                                hipStream_t s);
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 *buf0, const u64 *buf1,
