@@ -11,7 +11,7 @@
 //             ranks a tile of keys in LDS, stages it digit-sorted and writes each digit's run
 //             contiguously (level_scatter).  The level-0 node reads the packed dna directly: the
 //             extraction is fused, the raw keys are never materialised.
-//   leaves    a node of <= LEAF_CAP keys is sorted in LDS (counting sort on its top 12 free bits,
+//   leaves    a node of <= LEAF_CAP keys is sorted in LDS (counting sort on its top 13 free bits,
 //             then exact ranks inside each small bin), run-length encoded, and written at the
 //             offset a chained scan over the leaves (in key order) hands it.
 //   A node whose bits are exhausted holds one distinct key: it is emitted as (key, len) directly,
@@ -1156,7 +1156,8 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 //   * T = u32 (members of a bin differ only below bit 32): "precedes" is ONE 64-bit compare of
 //     {low dword, staged position} pairs.
 template <int NT, int ITEMS, typename T>
-__device__ __forceinline__ void rank_in_bins(const u64 *A, const u32 *H, const u32 *uniform_bits, u32 len, int sshift,
+__device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short *H, const u32 *uniform_bits, u32 len,
+                                             int sshift,
                                              u32 smask, u32 nbig, u64 (&key)[ITEMS], u32 (&pos)[ITEMS])
 {
     const int tid = threadIdx.x;
@@ -1277,17 +1278,20 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 {
     constexpr bool BIG = CAP > LEAF_CAP_SMALL;
     constexpr int ITEMS = CAP / NT;            // keys per thread
-    constexpr int BINS = 4096;                 // counting-sort bins (mean occupancy 0.5-1.4)
-    constexpr int BPT = BINS / NT;             // consecutive bins per thread in the scan (4 or 8)
-    constexpr int SB = 12;
+    constexpr int BINS = 8192;                 // counting-sort bins (mean occupancy 0.35-0.7), 16-bit counters:
+    constexpr int WPT = BINS / 2 / NT;         // two bins per LDS word, WPT consecutive words per thread in the scan
+    constexpr int SB = 13;
     constexpr int WAVES = NT / 64;
     constexpr int ROWS = ITEMS * WAVES;        // 64-position rows of the staged leaf
     constexpr u32 BIG_BIN = 24;
     static_assert(ROWS * 64 == CAP && ROWS <= 128, "one wave scans the rows' head counts, two per lane");
-    static_assert((1 << SB) == BINS && BPT % 4 == 0, "bins");
+    static_assert((1 << SB) == BINS && WPT % 4 == 0 && BINS / 2 + 1 <= CAP + 8 && CAP < 65536, "bins");
 
     __shared__ __attribute__((aligned(16))) u64 A[CAP];
-    __shared__ __attribute__((aligned(16))) u32 H[CAP + 8];   // bins -> offsets; later head positions
+    // bins (two 16-bit counters per word: a leaf holds fewer than 65536 keys, so a returning 32-bit add
+    // of 1 or 1 << 16 never carries between the halves) -> offsets; later, as 32-bit words, head positions
+    __shared__ __attribute__((aligned(16))) u32 H[CAP + 8];
+    const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     __shared__ u32 rowcnt[ROWS];               // [row][wave] head counts -> exclusive offsets
     __shared__ u32 wtmp[WAVES];
     __shared__ u32 sh_D;
@@ -1342,8 +1346,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
 
         if (sorted_path) {
 #pragma unroll
-            for (int q = 0; q < BPT / 4; q++)
-                reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q] = make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < WPT / 4; q++)
+                reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q] = make_uint4(0, 0, 0, 0);
             if (tid == 0)
                 big_n = 0;
             __syncthreads();
@@ -1355,19 +1359,26 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 rank[j] = 0;
                 // (slots past the end of the leaf take no part: an atomic on one shared dummy bin
                 // would serialise a third of the workgroup on a single LDS address)
-                if (i < len)
-                    rank[j] = atomicAdd(&H[(u32)(key[j] >> sshift) & smask], 1u);
+                if (i < len) {
+                    const u32 b = (u32)(key[j] >> sshift) & smask;
+                    const u32 sh16 = (b & 1u) * 16u;
+                    rank[j] = (atomicAdd(&H[b >> 1], 1u << sh16) >> sh16) & 0xffffu;
+                }
             }
             __syncthreads();
             STAMP(2);  // count (incl. waiting for the keys)
-            {   // exclusive scan of the bins, BPT consecutive bins per thread (16-byte LDS accesses)
-                uint4 v[BPT / 4];
+            {   // exclusive scan of the bins, 2 * WPT consecutive bins per thread (16-byte LDS accesses)
+                uint4 v[WPT / 4];
                 u32 sum = 0, cmax = 0;
 #pragma unroll
-                for (int q = 0; q < BPT / 4; q++) {
-                    v[q] = reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q];
-                    sum += v[q].x + v[q].y + v[q].z + v[q].w;
-                    cmax = max(max(cmax, max(v[q].x, v[q].y)), max(v[q].z, v[q].w));
+                for (int q = 0; q < WPT / 4; q++) {
+                    v[q] = reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q];
+                    const u32 w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        sum += (w[e] & 0xffffu) + (w[e] >> 16);
+                        cmax = max(cmax, max(w[e] & 0xffffu, w[e] >> 16));
+                    }
                 }
                 if (cmax > BIG_BIN)                 // rare: some bin holds many copies of few keys
                     big_n = 1;                      // (benign race: every writer stores 1)
@@ -1383,17 +1394,18 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                         base += (u32)__builtin_amdgcn_readlane((int)ws, wv - 1);
                 }
 #pragma unroll
-                for (int q = 0; q < BPT / 4; q++) {
-                    uint4 o;
-                    o.x = base;
-                    o.y = o.x + v[q].x;
-                    o.z = o.y + v[q].y;
-                    o.w = o.z + v[q].z;
-                    base = o.w + v[q].w;
-                    reinterpret_cast<uint4 *>(H)[tid * (BPT / 4) + q] = o;
+                for (int q = 0; q < WPT / 4; q++) {
+                    u32 w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const u32 c0 = w[e] & 0xffffu, c1 = w[e] >> 16;
+                        w[e] = base | ((base + c0) << 16);
+                        base += c0 + c1;
+                    }
+                    reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 if (tid == 0)
-                    H[BINS] = len;
+                    H[BINS / 2] = len;              // H16[BINS]: the end of the last bin
             }
             __syncthreads();
             STAMP(3);  // scan
@@ -1401,7 +1413,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             for (int j = 0; j < ITEMS; j++) {
                 u32 i = tid + j * NT;
                 if (i < len)
-                    A[H[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
+                    A[H16[(u32)(key[j] >> sshift) & smask] + rank[j]] = key[j];
             }
             __syncthreads();
             STAMP(4);  // place
@@ -1417,7 +1429,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     big_cnt = 0;
                 __syncthreads();
                 for (u32 b = tid; b < (u32)BINS; b += NT)
-                    if (H[b + 1] - H[b] > BIG_BIN) {
+                    if ((u32)H16[b + 1] - (u32)H16[b] > BIG_BIN) {
                         u32 slot = atomicAdd(&big_cnt, 1u);
                         if (slot < 64)
                             big_list[slot] = b;
@@ -1426,7 +1438,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 nbig = big_cnt < 64 ? big_cnt : 64;
                 for (u32 e = wave; e < nbig; e += WAVES) {
                     const u32 b = big_list[e];
-                    const u32 s0 = H[b], s1 = H[b + 1];
+                    const u32 s0 = H16[b], s1 = H16[b + 1];
                     const u64 k0 = A[s0];
                     bool same = true;
                     for (u32 m = s0 + lane; m < s1; m += 64)
@@ -1439,9 +1451,9 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
             if (rem > sb && !(dbg & 1)) {
                 // exact position inside each (small) bin: thread i ranks the key staged at i
                 if (sshift <= 32)
-                    rank_in_bins<NT, ITEMS, u32>(A, H, uniform_bits, len, sshift, smask, nbig, key, rank);
+                    rank_in_bins<NT, ITEMS, u32>(A, H16, uniform_bits, len, sshift, smask, nbig, key, rank);
                 else
-                    rank_in_bins<NT, ITEMS, u64>(A, H, uniform_bits, len, sshift, smask, nbig, key, rank);
+                    rank_in_bins<NT, ITEMS, u64>(A, H16, uniform_bits, len, sshift, smask, nbig, key, rank);
                 __syncthreads();
                 STAMP(5);  // in-bin rank
 #pragma unroll
