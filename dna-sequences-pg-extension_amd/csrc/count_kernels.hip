@@ -38,6 +38,14 @@ namespace dnagpu {
 
 // Diagnostic build only (make STAMPS=1): thread 0 of every workgroup accumulates shader-clock cycles
 // per phase of the scatter / leaves kernels; DNAGPU_STAMPS=1 prints the totals after each launch.
+// The same build honours the experiment switches read through diag_env() -- timing ablations that
+// make results INVALID (DNAGPU_DEBUG_SCATTER / DNAGPU_DEBUG_LEAVES) and shape experiments that are
+// only valid for some trees (DNAGPU_WC_NTH, DNAGPU_L1_BITS).  The product build ignores them.
+#ifdef DNAGPU_STAMPS
+static inline const char *diag_env(const char *name) { return getenv(name); }
+#else
+static inline const char *diag_env(const char *) { return nullptr; }
+#endif
 #ifdef DNAGPU_STAMPS
 __device__ unsigned long long g_stamps[32];
 #define STAMP_DECL unsigned long long st_acc[12] = {0}; unsigned long long st_last = __builtin_readcyclecounter();
@@ -205,7 +213,7 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
         return hipSuccess;
     static int l1_cap = 0;
     if (l1_cap == 0) {
-        const char *e = getenv("DNAGPU_L1_BITS");         // experiment: cap the split width of levels >= 1
+        const char *e = diag_env("DNAGPU_L1_BITS");         // experiment: cap the split width of levels >= 1
         l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
     }
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
@@ -1045,7 +1053,7 @@ static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, con
     static_assert(NT * ITEMS == SC_TILE, "tile size is fixed");
     static int dbg = -1;
     if (dbg < 0) {
-        const char *e = getenv("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results are invalid when set
+        const char *e = diag_env("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results are invalid when set
         dbg = e ? atoi(e) : 0;
     }
     if (src_dna)
@@ -1087,13 +1095,13 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS, 512));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            const char *e = getenv("DNAGPU_WC_NTH");      // experiment: 512-thread workgroups (needs splits <= 9 bits)
+            const char *e = diag_env("DNAGPU_WC_NTH");      // experiment: 512-thread workgroups (needs splits <= 9 bits)
             nth_keys = e ? atoi(e) : 1024;
             attr_set = true;
         }
         static int wdbg = -1;
         if (wdbg < 0) {
-            const char *e = getenv("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results invalid when set
+            const char *e = diag_env("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results invalid when set
             wdbg = e ? atoi(e) : 0;
         }
         if (src_dna && flt_span != ~0u)           // sharded count: sweep the whole sequence, keep this owner's keys
@@ -1614,7 +1622,7 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 
         return hipSuccess;
     static int dbg = -1, variant = 0, mult = 1;
     if (dbg < 0) {
-        const char *e = getenv("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
+        const char *e = diag_env("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
         dbg = e ? atoi(e) : 0;
         const char *v = getenv("DNAGPU_LEAVES_VARIANT");
         variant = v ? atoi(v) : 0;                       // 1024 threads x 4 keys, 64 VGPRs: 2 workgroups = 32 waves per CU
