@@ -344,7 +344,9 @@ def test_count_reference_groups(ctx, ref_vectors, survey_vectors):
         d.free()
 
 
-COUNT_SIZES = [1, 2, 100, 4095, 4096, 4097, 8193, 50_000, 1_000_003]
+# 6143-6145: the leaf capacity; 1_000_003: leaves around 3900 keys (both leaf classes in one list);
+# 1_400_000: leaves around 5470 keys (the six-keys-per-thread class only)
+COUNT_SIZES = [1, 2, 100, 4095, 4096, 4097, 6143, 6144, 6145, 8193, 50_000, 1_000_003, 1_400_000]
 
 
 @pytest.mark.parametrize("n", COUNT_SIZES)
