@@ -1,6 +1,10 @@
 // Microbenchmark: HBM write bandwidth when every wave-store instruction (64 lanes x 8 B) is split into
 // runs of RUN bytes landing at pseudo-random, run-aligned or unaligned places of a large buffer.
 // Informs the tile/radix choice of level_scatter (keys per digit per tile = run length).
+// NOTE: this kernel divides by run_keys per key and uses temporal stores, so its plateau (3.0 TB/s)
+// is ALU/temporal-store bound, not the memory system's: rw_mix.hip (shifts, nontemporal stores)
+// supersedes it -- sequential writes reach 6.0-6.5 TB/s, 128-byte runs 4.3 TB/s.  The ratio between
+// aligned and unaligned runs measured here stands.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
