@@ -1293,12 +1293,15 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     constexpr int ROWS = ITEMS * WAVES;        // 64-position rows of the staged leaf
     constexpr u32 BIG_BIN = 24;
     static_assert(ROWS * 64 == CAP && ROWS <= 128, "one wave scans the rows' head counts, two per lane");
-    static_assert((1 << SB) == BINS && WPT % 4 == 0 && BINS / 2 + 1 <= CAP + 8 && CAP < 65536, "bins");
+    static_assert((1 << SB) == BINS && WPT % 4 == 0 && CAP < 65536, "bins");
 
     __shared__ __attribute__((aligned(16))) u64 A[CAP];
     // bins (two 16-bit counters per word: a leaf holds fewer than 65536 keys, so a returning 32-bit add
-    // of 1 or 1 << 16 never carries between the halves) -> offsets; later, as 32-bit words, head positions
-    __shared__ __attribute__((aligned(16))) u32 H[CAP + 8];
+    // of 1 or 1 << 16 never carries between the halves) -> offsets.  Zeroed for the NEXT leaf as soon as
+    // this leaf's ranking is done (the head positions have their own table), so a leaf starts counting
+    // right behind its first barrier.
+    __shared__ __attribute__((aligned(16))) u32 H[BINS / 2 + 8];
+    __shared__ unsigned short P[CAP + 8];      // position of the q-th run head
     const unsigned short *H16 = reinterpret_cast<const unsigned short *>(H);
     __shared__ u32 rowcnt[ROWS];               // [row][wave] head counts -> exclusive offsets
     __shared__ u32 wtmp[WAVES];
@@ -1326,6 +1329,11 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         }
     }
 
+#pragma unroll
+    for (int q = 0; q < WPT / 4; q++)              // (every later leaf zeroes the bins for its successor)
+        reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q] = make_uint4(0, 0, 0, 0);
+    if (tid == 0)
+        big_n = 0;
     STAMP_DECL
     for (;;) {
         u32 ln = li + gridDim.x;
@@ -1353,13 +1361,6 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         u32 headbits = 0;                          // bit j: this thread's slot j starts a run
 
         if (sorted_path) {
-#pragma unroll
-            for (int q = 0; q < WPT / 4; q++)
-                reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q] = make_uint4(0, 0, 0, 0);
-            if (tid == 0)
-                big_n = 0;
-            __syncthreads();
-            STAMP(1);  // zero bins
             u32 rank[ITEMS];
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
@@ -1468,9 +1469,15 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 for (int j = 0; j < ITEMS; j++)
                     if (tid + j * NT < len)
                         A[rank[j]] = key[j];
-                __syncthreads();
-                STAMP(6);  // write back sorted
             }
+            // the bins are dead (every read of them is behind a barrier): zero them for the next leaf
+#pragma unroll
+            for (int q = 0; q < WPT / 4; q++)
+                reinterpret_cast<uint4 *>(H)[tid * (WPT / 4) + q] = make_uint4(0, 0, 0, 0);
+            if (tid == 0)
+                big_n = 0;
+            __syncthreads();
+            STAMP(6);  // write back sorted
         }
 
         // ---- the sort no longer needs key[]: the next leaf's loads are issued below, behind wave
@@ -1559,10 +1566,10 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 const bool head = (headbits >> j) & 1;
                 const u64 hbj = __ballot(head);    // (recomputed: eight live ballots cost 16 SGPRs)
                 if (head)
-                    H[rowcnt[j * WAVES + wave] + (u32)__popcll(hbj & below)] = tid + j * NT;
+                    P[rowcnt[j * WAVES + wave] + (u32)__popcll(hbj & below)] = (unsigned short)(tid + j * NT);
             }
             if (tid == 0)
-                H[D] = len;
+                P[D] = (unsigned short)len;
             // (H as bin offsets is dead: every read of it happened before the barriers above)
         }
         if (wave == 0 && lane == 63) {
@@ -1585,9 +1592,9 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                 }
             } else {
                 for (u32 q2 = tid; q2 < D; q2 += NT) {
-                    u32 p = H[q2];
+                    const u32 p = P[q2];
                     NT_STORE(A[p], &out_keys[obase + q2]);
-                    NT_STORE((u32)(H[q2 + 1] - p), &out_counts[obase + q2]);
+                    NT_STORE((u32)P[q2 + 1] - p, &out_counts[obase + q2]);
                 }
             }
         }
