@@ -221,10 +221,11 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void fill_chunks_kernel(const Node *__restrict__ nodes, u32 n_nodes,
+// (nodes and nodes_rw are the same array: no __restrict__ on them)
+__global__ __launch_bounds__(256) void fill_chunks_kernel(const Node *nodes, u32 n_nodes,
                                                           u32 chunk_len, const u32 *__restrict__ child_base,
                                                           const u32 *__restrict__ chunk_base,
-                                                          Node *__restrict__ nodes_rw, Chunk *__restrict__ chunks)
+                                                          Node *nodes_rw, Chunk *__restrict__ chunks)
 {
     // one node per blockIdx.x-row of 64 lanes: the lanes share the node's chunks (the dna root alone has thousands)
     const u32 i = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
