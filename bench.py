@@ -30,12 +30,14 @@ SEED = 0xD2A0003
 CPU_SAMPLE_BASES = 24_000_000  # bounded sample for the CPU baseline (about 10-20 s on one core)
 
 # algorithmic HBM bytes of each phase per k-mer (n) / per distinct k-mer (d); DESIGN.md "kernels"
+# (n = this rank's k-mers, d = its distinct k-mers, N = k-mers of the whole sequence: a sharded rank sweeps
+# all of the packed sequence at level 0 and keeps its own key range)
 PHASE_BYTES = {
-    "hist0": lambda n, d: 0.25 * n,                 # packed input only
-    "scatter0": lambda n, d: 0.25 * n + 8.0 * n,    # packed input in, keys out
-    "hist": lambda n, d: 8.0 * n,                   # keys in
-    "scatter": lambda n, d: 16.0 * n,               # keys in, keys out
-    "leaves": lambda n, d: 8.0 * n + 12.0 * d,      # keys in, (u64 key, u32 count) groups out
+    "hist0": lambda n, d, N: 0.25 * N,              # packed input only
+    "scatter0": lambda n, d, N: 0.25 * N + 8.0 * n,  # packed input in, keys out
+    "hist": lambda n, d, N: 8.0 * n,                # keys in
+    "scatter": lambda n, d, N: 16.0 * n,            # keys in, keys out
+    "leaves": lambda n, d, N: 8.0 * n + 12.0 * d,   # keys in, (u64 key, u32 count) groups out
 }
 
 
@@ -149,7 +151,7 @@ def main():
         if dom:
             per_rank_n = n_kmers / world
             per_rank_d = distinct[0] / world
-            alg_bytes = PHASE_BYTES[phase_kind(dom)](per_rank_n, per_rank_d)
+            alg_bytes = PHASE_BYTES[phase_kind(dom)](per_rank_n, per_rank_d, n_kmers)
             achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
