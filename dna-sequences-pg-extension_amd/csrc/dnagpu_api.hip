@@ -1033,7 +1033,57 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     }
     prof_begin(ctx);
     int rc;
-    {
+    if (dna && n_owners == 1 && fixed_bits == 0 && 2 * k <= dense_max_bits() && n > (u64)LEAF_CAP &&
+        n >= ((u64)(2 * k > 16 ? 64 : 4) << (2 * k))) {   // (enough rows to pay for the passes and for compacting the table)
+        // short k-mers: the histogram is a table of at most 262,144 counters filled straight from the
+        // packed sequence (no key is ever written); one segment, keys ascending
+        PoolScope ps(ctx);
+        const int bits = 2 * k;
+        const size_t n_bins = (size_t)1 << bits;
+        u32 *table = nullptr, *oc = nullptr, *seg_cnt = nullptr;
+        u64 *ok = nullptr, *seg_off = nullptr, *n_out = nullptr;
+        rc = ps.alloc(n_bins, &table);
+        if (rc == DNAGPU_OK) rc = ps.alloc(n_bins, &ok);
+        if (rc == DNAGPU_OK) rc = ps.alloc(n_bins, &oc);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &seg_off);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &seg_cnt);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &n_out);
+        u64 D = 0;
+        if (rc == DNAGPU_OK) {
+            prof_mark(ctx, "dense_count");
+            hipError_t e = launch_dense_count(dna->words, dna->n_words, first, n, bits, table, ok, oc, n_out, ctx->stream);
+            prof_mark(ctx, "end");
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(&D, n_out, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+            const u64 zero = 0;
+            const u32 d32 = (u32)D;
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(seg_off, &zero, 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(seg_cnt, &d32, 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                set_err("dense count: %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            }
+        }
+        if (rc == DNAGPU_OK) {
+            h->total = n;
+            h->n_distinct = D;
+            h->keys = ok;
+            h->counts = oc;
+            h->seg_off = seg_off;
+            h->seg_cnt = seg_cnt;
+            h->n_segs = 1;
+            ps.release(ok);
+            ps.release(oc);
+            ps.release(seg_off);
+            ps.release(seg_cnt);
+        }
+    } else {
         PoolScope ps(ctx);
         TreeResult tr;
         if (n_owners > 1) {

@@ -103,6 +103,11 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
+// dense count of short k-mers straight from the packed sequence (2k = bits <= dense_max_bits()): table must hold
+// 2^bits u32 counters, out_keys/out_counts 2^bits entries; *n_out = distinct keys; results ascending
+int dense_max_bits();
+hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, u64 *out_keys,
+                              u32 *out_counts, u64 *n_out, hipStream_t s);
 // groups [first, first+count) of the ascending-key view -> dst arrays
 hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
                                 u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,

@@ -366,6 +366,36 @@ def test_count_random(ctx, n):
     d.free()
 
 
+@pytest.mark.parametrize("n,ks", [(300_007, (1, 4, 7, 8)), (5_000_011, (2, 5, 6, 7, 8)), (17_000_003, (9,))])
+def test_count_dense_short_kmers(ctx, n, ks):
+    """2k <= 18 bits and enough rows: the dense table path (no tree).  Whole sequence, a window, a
+    repeat-rich input and poly-A (every window on one counter)."""
+    words = orc.synth_words(4242 + n, n)
+    d = ctx.upload(words, n)
+    for k in ks:
+        ok, oc = orc.count_kmers(words, n, k)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"dense n={n} k={k}")
+        assert h.total == n - k + 1
+        h.free()
+    k = ks[-1]
+    first, cnt = 12345, n - 100_000
+    keys = orc.generate_kmers(words, n, k, first, cnt, faithful=False)
+    ok, oc = orc.count_keys(keys)
+    h = ctx.count_kmers(d, k, first, cnt)
+    check_hist(h, ok, oc, f"dense window n={n} k={k}")
+    h.free()
+    d.free()
+    if n < 10_000_000:
+        for words2 in (orc.synth_words_repeat(7, n, 1000), orc.dna_encode("A" * n)[0]):
+            d2 = ctx.upload(words2, n)
+            ok, oc = orc.count_kmers(words2, n, k)
+            h = ctx.count_kmers(d2, k)
+            check_hist(h, ok, oc, f"dense skewed n={n} k={k}")
+            h.free()
+            d2.free()
+
+
 def test_count_faithful_oracle(ctx):
     # the oracle's faithful path (per-base decode + re-encode + hash aggregate), config-1 shaped
     n = 200_000
