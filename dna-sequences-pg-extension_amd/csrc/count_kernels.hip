@@ -190,13 +190,19 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         }                                       // (a leaf just over the capacity is halved)
         bits = want;
         if (rem <= MAX_SPLIT_BITS) bits = rem;  // the rest of the key fits one digit: terminal split, no key moves
+        else if (rem <= 2 * MAX_SPLIT_BITS && bits < rem - MAX_SPLIT_BITS)
+            bits = rem - MAX_SPLIT_BITS;        // ... fits two: leave one digit, so the next level is terminal
         if (bits > MAX_SPLIT_BITS) bits = MAX_SPLIT_BITS;
         if (level >= 1 && bits > l1_cap) bits = l1_cap;
         if (bits > rem) bits = rem;
         if (bits < 1) bits = 1;
     }
-    if (bits == 0 && rem > 0 && !(nd.meta & NODE_TERMINAL) && nd.len > (u32)LEAF_CAP_SMALL)
+    // (fixed addresses, so that the compiler folds each into one atomic per wave)
+    const bool sorts = bits == 0 && nd.len > 0 && rem > 0 && !(nd.meta & NODE_TERMINAL);
+    if (sorts && nd.len > (u32)LEAF_CAP_SMALL)
         atomicAdd(&ctr->n_big, 1u);
+    if (sorts && nd.len <= (u32)LEAF_CAP_SMALL)
+        atomicAdd(&ctr->n_small, 1u);
     nodes[i].split = (u32)bits;
     outc[i] = bits ? (1u << bits) : 1u;
     nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
@@ -1248,7 +1254,7 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short 
 __device__ __forceinline__ bool leaf_in_class(const Node &nd, bool big_class)
 {
     const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
-    return (sorts && nd.len > (u32)LEAF_CAP_SMALL) == big_class;
+    return sorts && (nd.len > (u32)LEAF_CAP_SMALL) == big_class;   // (single-key and empty nodes: emit_singles_kernel)
 }
 
 // The first leaf of the class at or behind `from`, in steps of `step` (n_leaves if none): the 64 lanes
@@ -1625,8 +1631,48 @@ static u32 leaves_grid(u32 n_leaves, int per_cu)
     return n_leaves < g ? n_leaves : g;
 }
 
-hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 *buf0, const u64 *buf1,
-                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
+// Nodes that hold one distinct key (their bits are exhausted: heavy hitters, short k-mers after a
+// terminal split) or none need no sorting: they are emitted in bulk, in node (= key) order, into the
+// first slots of the output; the sorting leaves then take their ranges from the cursor behind them.
+// (Sent through the leaves kernel one workgroup iteration each, a million of them cost 10 ms.)
+__global__ __launch_bounds__(256) void single_flags_kernel(const Node *__restrict__ leaves, u32 n_leaves,
+                                                           u32 *__restrict__ flags)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves)
+        return;
+    const Node nd = leaves[i];
+    const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
+    flags[i] = (!sorts && nd.len > 0) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restrict__ leaves, u32 n_leaves,
+                                                           const u32 *__restrict__ pre, const u32 *__restrict__ total,
+                                                           unsigned long long *__restrict__ cursor,
+                                                           u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                           u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        *cursor = *total;                          // the sorting leaves allocate behind the singles
+    if (i >= n_leaves)
+        return;
+    const Node nd = leaves[i];
+    const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
+    if (sorts)
+        return;
+    const u32 o = pre[i];
+    seg_off[i] = o;
+    seg_cnt[i] = nd.len > 0 ? 1u : 0u;
+    if (nd.len > 0) {
+        out_keys[o] = nd.prefix;
+        out_counts[o] = nd.len;
+    }
+}
+
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
+                         u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
+                         u32 *scan_tmp, hipStream_t s)
 {
     if (n_leaves == 0)
         return hipSuccess;
@@ -1642,10 +1688,19 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 
             mult = 1;
     }
     unsigned long long *cur = reinterpret_cast<unsigned long long *>(cursor);
-    const bool mixed = n_big > 0 && n_big < n_leaves;
-#define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_)                                                                        \
+    if (n_small + n_big < n_leaves) {                    // single-key and empty nodes
+        const u32 g = (n_leaves + 255) / 256;
+        hipLaunchKernelGGL(single_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, flags);
+        hipError_t e = launch_scan_u32(flags, flags, n_leaves, scan_tmp, flags + n_leaves, s);   // (flags holds n_leaves + 1)
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(emit_singles_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, flags, flags + n_leaves, cur,
+                           seg_off, seg_cnt, out_keys, out_counts);
+    }
+    const bool mixed_small = n_small < n_leaves, mixed_big = n_big < n_leaves;
+#define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_, MIXED_)                                                                        \
     do {                                                                                                              \
-        if (mixed)                                                                                                    \
+        if (MIXED_)                                                                                                   \
             hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),   \
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
                                out_counts, dbg);                                                                      \
@@ -1654,16 +1709,16 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_big, const u64 
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
                                out_counts, dbg);                                                                      \
     } while (0)
-    if (n_big < n_leaves) {                              // leaves of at most LEAF_CAP_SMALL keys (and single-key nodes)
+    if (n_small > 0) {                                   // leaves of at most LEAF_CAP_SMALL keys
         if (variant == 2)
-            LAUNCH_LEAVES(1024, 4, LEAF_CAP_SMALL, 1);
+            LAUNCH_LEAVES(1024, 4, LEAF_CAP_SMALL, 1, mixed_small);
         else if (variant == 3)
-            LAUNCH_LEAVES(512, 4, LEAF_CAP_SMALL, 2);
+            LAUNCH_LEAVES(512, 4, LEAF_CAP_SMALL, 2, mixed_small);
         else
-            LAUNCH_LEAVES(1024, 8, LEAF_CAP_SMALL, 2);
+            LAUNCH_LEAVES(1024, 8, LEAF_CAP_SMALL, 2, mixed_small);
     }
     if (n_big > 0)                                       // leaves of up to LEAF_CAP keys
-        LAUNCH_LEAVES(1024, 8, LEAF_CAP, 2);
+        LAUNCH_LEAVES(1024, 8, LEAF_CAP, 2, mixed_big);
 #undef LAUNCH_LEAVES
 #ifdef DNAGPU_STAMPS
     stamps_report("leaves", 0, s);
