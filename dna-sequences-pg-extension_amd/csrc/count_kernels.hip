@@ -185,9 +185,12 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         if (level == 0) {
             if (want > MAX_SPLIT_BITS)
                 want = (want + 1) / 2;          // two balanced levels
-        } else if (level >= 2 && nd.len > 4u * (u32)LEAF_CAP) {
-            want += 4;                          // a far oversize survivor is skewed: fan out harder
-        }                                       // (a leaf just over the capacity is halved)
+        } else if (level >= 2) {
+            // An oversize node this deep is skew, not chance (planned leaves sit >= 4.5 sigma under the capacity):
+            // typically one heavy k-mer plus a leaf's worth of others.  Fan out at full width, so that the heavy
+            // key is alone -- and its node recognised as constant by level_hist -- two levels on, not ten.
+            want = MAX_SPLIT_BITS;
+        }
         bits = want;
         if (rem <= MAX_SPLIT_BITS) bits = rem;  // the rest of the key fits one digit: terminal split, no key moves
         else if (rem <= 2 * MAX_SPLIT_BITS && bits < rem - MAX_SPLIT_BITS)
@@ -349,9 +352,11 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                                                                 u64 first, u64 mask,
                                                                 const u64 *__restrict__ buf0,
                                                                 const u64 *__restrict__ buf1,
-                                                                u32 *__restrict__ hist, DigitFilter flt)
+                                                                u32 *__restrict__ hist, DigitFilter flt,
+                                                                u32 *__restrict__ vary)
 {
     __shared__ u32 h[ROW_STRIDE];
+    __shared__ u32 sh_vary;
     if (blockIdx.x >= n_chunks)
         return;
     const Chunk ch = chunks[blockIdx.x];
@@ -383,9 +388,29 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
             }
         }
     } else {
+        // Besides the digit counts: how many low key bits VARY inside the node (64 - clz of the OR of
+        // key ^ the node's first key).  A node whose keys all share this level's digit -- many copies of
+        // one k-mer, or of k-mers that differ only further down -- is then not moved at all: its single
+        // child stays in place and resumes at the first varying bit (level_children), terminal if none varies.
         const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + origin;
-        for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS)
-            atomicAdd(&h[(u32)(NT_LOAD(&src[i]) >> shift) & dmask], 1u);
+        const u64 ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];    // the node's first key
+        if (threadIdx.x == 0)
+            sh_vary = 0;
+        u64 v = 0;
+        for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
+            const u64 key = NT_LOAD(&src[i]);
+            v |= key ^ ref;
+            atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
+        }
+        if (vary) {
+            __syncthreads();
+            const u32 hb = v ? 64u - (u32)__builtin_clzll(v) : 0u;
+            if (hb > 0)                                 // (skipped by whole workgroups of identical keys)
+                atomicMax(&sh_vary, hb);
+            __syncthreads();
+            if (threadIdx.x == 0 && sh_vary > 0)
+                atomicMax(&vary[ch.node], sh_vary);
+        }
     }
     __syncthreads();
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;
@@ -395,17 +420,17 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
 
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s)
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, hipStream_t s)
 {
     const DigitFilter flt{flt_lo, flt_span, flt_tb};
     if (n_chunks == 0)
         return hipSuccess;
     if (src_dna)
         hipLaunchKernelGGL(level_hist_kernel<true>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, (u32 *)nullptr);
     else
         hipLaunchKernelGGL(level_hist_kernel<false>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, vary);
     return hipGetLastError();
 }
 
@@ -466,8 +491,13 @@ __global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slic
 // level_children: one workgroup per node.  Leaf: copied to its slot in the next list.  Split: the
 // per-digit totals are scanned over digits; child d becomes a node at start + excl[d]; the tot row
 // is overwritten with the absolute base of every digit (read by the scatter).
-__global__ __launch_bounds__(256) void level_children_kernel(const Node *__restrict__ nodes, u32 n_nodes,
-                                                             u32 *__restrict__ tot, Node *__restrict__ next)
+// vary != null (key-source levels): a node whose keys all share this level's digit is not scattered
+// (NODE_SKIP); its one non-empty child is the node itself, in place, with only the varying low bits left.
+__global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_nodes,
+                                                             u32 *__restrict__ tot, Node *__restrict__ next,
+                                                             const u32 *__restrict__ vary,
+                                                             const u64 *__restrict__ buf0,
+                                                             const u64 *__restrict__ buf1)
 {
     __shared__ u32 ex[ROW_STRIDE];
     __shared__ u32 wtmp[4];
@@ -501,8 +531,14 @@ __global__ __launch_bounds__(256) void level_children_kernel(const Node *__restr
     block_scan_inplace<256>(ex, (int)R, wtmp);
     const u32 child_meta = (u32)(rem - bits) | ((nd.meta & NODE_BUF) ^ NODE_BUF) |
                            ((bits == rem) ? NODE_TERMINAL : 0u);
-    const bool root_dna_child_buf0 = false;
-    (void)root_dna_child_buf0;
+    const u32 hv = vary ? vary[i] : 64u;
+    const bool stay = nd.len > 0 && hv <= (u32)(rem - bits) && bits < rem;
+    u64 ref = 0;
+    if (stay) {
+        ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];
+        if (threadIdx.x == 0)
+            nodes[i].meta = nd.meta | NODE_SKIP;
+    }
 #pragma unroll
     for (int q = 0; q < ROW_STRIDE / 256; q++) {
         u32 d = threadIdx.x + q * 256;
@@ -513,6 +549,10 @@ __global__ __launch_bounds__(256) void level_children_kernel(const Node *__restr
             c.meta = child_meta;
             c.split = 0;
             c.prefix = nd.prefix | ((u64)d << (rem - bits));
+            if (stay && c.len) {                  // the single non-empty child: the node's own keys, where they are
+                c.meta = hv | (nd.meta & NODE_BUF) | (hv == 0 ? NODE_TERMINAL : 0u);
+                c.prefix = (ref >> hv) << hv;
+            }
             c.child_base = 0;
             c.chunk_base = 0;
             next[nd.child_base + d] = c;
@@ -521,13 +561,14 @@ __global__ __launch_bounds__(256) void level_children_kernel(const Node *__restr
     }
 }
 
-hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *hist, Node *next, hipStream_t s)
+hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *hist, Node *next, const u32 *vary, const u64 *buf0,
+                                 const u64 *buf1, hipStream_t s)
 {
     // `hist` here is the tot table (same geometry as the hist table); the prefix kernel is launched
     // separately by the host through launch_level_prefix
     if (n_nodes == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(level_children_kernel, dim3(n_nodes), dim3(256), 0, s, nodes, n_nodes, hist, next);
+    hipLaunchKernelGGL(level_children_kernel, dim3(n_nodes), dim3(256), 0, s, nodes, n_nodes, hist, next, vary, buf0, buf1);
     return hipGetLastError();
 }
 
@@ -572,7 +613,7 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem)
+    if (bits == rem || (nd.meta & NODE_SKIP))
         return;                                   // terminal split: children carry (key, count) already
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;
@@ -728,7 +769,7 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem)
+    if (bits == rem || (nd.meta & NODE_SKIP))
         return;                                   // terminal split: nothing moves
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;
@@ -924,7 +965,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem)
+    if (bits == rem || (nd.meta & NODE_SKIP))
         return;                                   // terminal split: nothing moves
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;

@@ -972,14 +972,20 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         RC_TRY(ps.alloc((size_t)hc.n_chunks * ROW_STRIDE, &hist));
         RC_TRY(ps.alloc((size_t)hc.n_chunks * ROW_STRIDE, &tot));
         RC_TRY(ps.alloc(hc.n_next, &next));
+        // key-source levels: level_hist also finds, per node, how many low key bits vary (see level_children)
+        u32 *vary = nullptr;
+        if (!src_dna && !(force_bits > 0 && level == 0)) {
+            RC_TRY(ps.alloc(n_nodes, &vary));
+            HIP_TRY(hipMemsetAsync(vary, 0, (size_t)n_nodes * sizeof(u32), st));
+        }
         HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, chunks, st));
         prof_mark(ctx, LEVEL_HIST_NAMES[li]);
         HIP_TRY(launch_level_hist(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                   dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
-                                  src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, st));
+                                  src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, vary, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
         HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st));
-        HIP_TRY(launch_level_children(cur, n_nodes, tot, next, st));
+        HIP_TRY(launch_level_children(cur, n_nodes, tot, next, vary, buf0, buf1, st));
         if (src_dna) {
             // the dna root's children say how many keys survive the owner filter
             std::vector<Node> kids(hc.n_next);
@@ -1005,6 +1011,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         ps.free_now(chunks);
         ps.free_now(hist);
         ps.free_now(tot);
+        if (vary)
+            ps.free_now(vary);
         ps.free_now(cur);
         cur = next;
         n_nodes = hc.n_next;

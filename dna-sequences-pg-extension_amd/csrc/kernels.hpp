@@ -61,6 +61,7 @@ struct Node {           // 32 bytes
 };
 constexpr u32 NODE_BUF = 1u << 8;
 constexpr u32 NODE_TERMINAL = 1u << 9;
+constexpr u32 NODE_SKIP = 1u << 10;     // this level only: all keys share the digit, the scatter leaves the node where it is
 
 struct Chunk {          // 16 bytes: a contiguous piece of one node, the unit of work of a level
     u32 node;
@@ -88,14 +89,17 @@ hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, con
 // aligned power-of-two range and only the digit's top tb bits need testing)
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, hipStream_t s);
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, hipStream_t s);
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
                                u32 *hist, u32 *tot, hipStream_t s);
 // per node: leaf -> copied to the next list; split -> totals scanned over digits, children appended
 // in digit (= key) order, tot row overwritten with each digit's absolute base
-hipError_t launch_level_children(const Node *nodes, u32 n_nodes, u32 *tot, Node *next, hipStream_t s);
+// vary (may be null): per node, the number of low key bits that vary inside it, as level_hist found (key-source
+// levels); a node whose keys all share this level's digit is flagged NODE_SKIP and stays where it is
+hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *tot, Node *next, const u32 *vary, const u64 *buf0,
+                                 const u64 *buf1, hipStream_t s);
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
                                 const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 max_bits,
