@@ -435,6 +435,43 @@ def test_count_low_complexity(ctx, seq):
     d.free()
 
 
+def _heavy_hitter_words(kind, n):
+    """random sequences with heavy k-mers planted word-aligned (numpy only: no reference involved)"""
+    nw = (n + 31) // 32
+    rng = np.random.default_rng(len(kind) * 1000 + n)
+    w = rng.integers(0, 2**63, nw, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, nw, dtype=np.uint64)
+    if kind == "motif":                       # a 64-base motif 9000 times: 34 k-mers (k=31) just over a leaf each
+        step = (nw // 9000) & ~1
+        w[0:step * 9000:step] = np.uint64(0x1234567890ABCDEF)
+        w[1:step * 9000:step] = np.uint64(0x0FEDCBA987654321)
+    elif kind == "half-polyA":                # one k-mer with half of all rows, sharing its top digits with others
+        w[: nw // 2] = 0
+    elif kind == "two-heavy":                 # two heavy k-mers that differ in their lowest base only
+        w[: nw // 3] = 0
+        w[nw // 3: 2 * nw // 3] = np.uint64(0x0000000100000001)
+    elif kind == "tandem":                    # a 224-base tandem repeat: 224 k-mers, each with 1/224 of the rows
+        w = np.tile(w[:7], nw // 7 + 1)[:nw].copy()
+    r = n % 32
+    if r:
+        w[-1] &= np.uint64((1 << (2 * r)) - 1)
+    return w
+
+
+@pytest.mark.parametrize("kind,n", [("motif", 12_000_000), ("half-polyA", 3_000_001), ("two-heavy", 2_500_000),
+                                    ("tandem", 4_000_000)])
+def test_count_heavy_hitters(ctx, kind, n):
+    """nodes that stay in place (constant, or common prefix) and deep full-width splits: count_kernels.hip
+    level_hist/level_children; the oracle is the checker"""
+    words = _heavy_hitter_words(kind, n)
+    d = ctx.upload(words, n)
+    for k in ((31,) if kind == "motif" else (12, 21, 31, 32)):
+        ok, oc = orc.count_kmers(words, n, k)
+        h = ctx.count_kmers(d, k)
+        check_hist(h, ok, oc, f"heavy hitters {kind} n={n} k={k}")
+        h.free()
+    d.free()
+
+
 def test_count_windows_and_linearity(ctx):
     n, k = 700_000, 21
     words = orc.synth_words_repeat(8, n, 5000)
