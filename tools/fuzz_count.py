@@ -27,6 +27,23 @@ with pkg.Context(0) as ctx:
         else:
             motif = 0
             words = orc.synth_words(seed, n)
+        planted = 0
+        if rng.random() < 0.35 and len(words) > 8:        # heavy hitters: constant stretches and strided motifs
+            words = words.copy()
+            nw = len(words)
+            for _ in range(int(rng.integers(1, 4))):
+                planted += 1
+                val = np.uint64(rng.choice([0, 0x4444444444444444, 0x0000000100000001, int(rng.integers(0, 2**63))]))
+                if rng.random() < 0.5:
+                    lo = int(rng.integers(0, nw))
+                    words[lo:lo + int(rng.integers(1, max(nw // 2, 2)))] = val
+                else:
+                    step = int(rng.integers(2, max(nw // 50, 3))) & ~1
+                    words[0::step] = val
+                    words[1::step] = np.uint64(int(val) ^ 0x0FEDCBA987654321)
+            r = n % 32
+            if r:
+                words[-1] &= np.uint64((1 << (2 * r)) - 1)
         d = ctx.upload(words, n)
         nk = max(n - k + 1, 0)
         first = int(rng.integers(0, nk)) if nk and rng.random() < 0.3 else 0
@@ -52,7 +69,7 @@ with pkg.Context(0) as ctx:
         d.free()
         if not good:
             bad += 1
-            print(f"MISMATCH case {c}: n={n} k={k} seed={seed} motif={motif} first={first} count={count}", flush=True)
+            print(f"MISMATCH case {c}: n={n} k={k} seed={seed} motif={motif} planted={planted} first={first} count={count}", flush=True)
         if c % 20 == 19:
             print(f"{c + 1} cases, {bad} mismatches, {time.time() - t_start:.0f} s", flush=True)
 print(f"done: {cases} cases, {bad} mismatches")
