@@ -25,7 +25,7 @@ FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2
 FILTER_CONTAINS = 3
 
-MAX_PHASES = 16
+MAX_PHASES = 48
 
 u64p = C.POINTER(C.c_uint64)
 

@@ -165,6 +165,18 @@ __device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
 
 // ------------------------------------------------------------------------------------------------
 // plan: one thread per node decides leaf / split width (see DESIGN.md "level plan")
+// nodes of the level that must split (read by plan_kernel to size the fan-out of deep levels)
+__global__ __launch_bounds__(256) void plan_count_kernel(const Node *__restrict__ nodes, u32 n_nodes,
+                                                         LevelCounters *__restrict__ ctr)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes)
+        return;
+    const Node nd = nodes[i];
+    if (nd.len > (u32)LEAF_CAP && (nd.meta & 0xff) > 0 && !(nd.meta & NODE_TERMINAL))
+        atomicAdd(&ctr->n_over, 1u);
+}
+
 __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32 n_nodes, int level,
                                                    u32 chunk_len, u32 *__restrict__ outc,
                                                    u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap)
@@ -187,9 +199,15 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
                 want = (want + 1) / 2;          // two balanced levels
         } else if (level >= 2) {
             // An oversize node this deep is skew, not chance (planned leaves sit >= 4.5 sigma under the capacity):
-            // typically one heavy k-mer plus a leaf's worth of others.  Fan out at full width, so that the heavy
-            // key is alone -- and its node recognised as constant by level_hist -- two levels on, not ten.
-            want = MAX_SPLIT_BITS;
+            // typically heavy k-mers plus a leaf's worth of others.  Fan out wider than the size asks for, so
+            // that a heavy key is soon alone (and its node recognised as constant by level_hist) -- as wide as
+            // a budget of 2^19 new nodes over all the level's oversize nodes allows: a few such nodes split
+            // 1024 ways (two more levels instead of ten), a hundred thousand of them only 4 ways (every child
+            // is a leaves-kernel iteration: 1024 ways there cost 75 ms at 1 Gbase).
+            const u32 over = ctr->n_over ? ctr->n_over : 1u;
+            const int extra = 31 - __builtin_clz(((1u << 19) / over) | 1u);
+            if (want < extra)
+                want = extra;
         }
         bits = want;
         if (rem <= MAX_SPLIT_BITS) bits = rem;  // the rest of the key fits one digit: terminal split, no key moves
@@ -227,6 +245,8 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
         const char *e = diag_env("DNAGPU_L1_BITS");         // experiment: cap the split width of levels >= 1
         l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
     }
+    if (level >= 2)
+        hipLaunchKernelGGL(plan_count_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, ctr);
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
                        chunk_len, outc, nch, ctr, l1_cap);
     return hipGetLastError();
@@ -1214,7 +1234,8 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 //   * T = u32 (members of a bin differ only below bit 32): "precedes" is ONE 64-bit compare of
 //     {low dword, staged position} pairs.
 template <int NT, int ITEMS, typename T>
-__device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short *H, const u32 *uniform_bits, u32 len,
+__device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short *H, const u32 *uniform_bits,
+                                             const unsigned short *P, u32 len,
                                              int sshift,
                                              u32 smask, u32 nbig, u64 (&key)[ITEMS], u32 (&pos)[ITEMS])
 {
@@ -1232,13 +1253,17 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short 
         lo[j] = l;
         size[j] = h - l;
     }
-    if (nbig > 0) {                                 // rare: a long bin of equal keys keeps its staged order
+    if (nbig > 0) {                                 // rare: the members of a long bin that a wave has placed already
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             const u32 b = (u32)(key[j] >> sshift) & smask;
-            if ((uniform_bits[b >> 5] >> (b & 31)) & 1) {
-                lo[j] = tid + j * NT;
-                size[j] = 0;
+            const u32 i = tid + j * NT;
+            if (i < len && ((uniform_bits[b >> 5] >> (b & 31)) & 1)) {
+                const u32 p = P[i];
+                if (p != 0xffffu) {
+                    lo[j] = p;
+                    size[j] = 0;
+                }
             }
         }
     }
@@ -1360,7 +1385,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     __shared__ u32 big_n;                      // nonzero: some bin of this leaf has more than BIG_BIN members
     __shared__ u32 big_cnt;
     __shared__ u32 big_list[64];
-    __shared__ u32 uniform_bits[BINS / 32];   // bit b: bin b is big and all its members are equal
+    __shared__ u32 uniform_bits[BINS / 32];   // bit b: bin b is long and a wave has placed its heavy members (P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 li = blockIdx.x;
@@ -1495,24 +1520,81 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                     }
                 __syncthreads();
                 nbig = big_cnt < 64 ? big_cnt : 64;
+                // One wave per long bin.  Up to MAX_PIVOTS times: the first member without a position is the
+                // pivot; count the members below it, then give every member EQUAL to it its final position
+                // (staged order among equals) -- two sweeps of members/64 steps per distinct heavy key.  Members
+                // still without a position after that (P = NO_POS: the bin holds many distinct keys) are ranked
+                // all-pairs by their own threads, as in a short bin.
+                constexpr u32 NO_POS = 0xffffu;
+                constexpr int MAX_PIVOTS = 32;
+                const u64 lane_lt = (1ull << lane) - 1ull;
                 for (u32 e = wave; e < nbig; e += WAVES) {
                     const u32 b = big_list[e];
                     const u32 s0 = H16[b], s1 = H16[b + 1];
-                    const u64 k0 = A[s0];
-                    bool same = true;
                     for (u32 m = s0 + lane; m < s1; m += 64)
-                        same &= A[m] == k0;
-                    if (__all(same) && lane == 0)
+                        P[m] = (unsigned short)NO_POS;
+                    __builtin_amdgcn_wave_barrier();
+                    u32 cursor = s0, placed = 0;
+                    for (int it = 0; it < MAX_PIVOTS && placed < s1 - s0; it++) {
+                        u32 pi = s1;
+                        for (u32 m0 = cursor; m0 < s1; m0 += 64) {
+                            const u32 m = m0 + lane;
+                            const u64 un = __ballot(m < s1 && P[m] == NO_POS);
+                            if (un) {
+                                pi = m0 + (u32)__builtin_ctzll(un);
+                                break;
+                            }
+                        }
+                        if (pi >= s1)
+                            break;
+                        cursor = pi + 1;
+                        const u64 k0 = A[pi];
+                        // (four independent LDS loads per step: the sweeps are latency bound)
+                        u32 below = 0;
+                        for (u32 m0 = s0; m0 < s1; m0 += 256) {
+                            u64 v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const u32 m = m0 + q * 64 + lane;
+                                v[q] = A[m < s1 ? m : s0];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                below += (u32)__popcll(__ballot(m0 + q * 64 + lane < s1 && v[q] < k0));
+                        }
+                        u32 run = s0 + below;
+                        for (u32 m0 = s0; m0 < s1; m0 += 256) {
+                            u64 v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const u32 m = m0 + q * 64 + lane;
+                                v[q] = A[m < s1 ? m : s0];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const u32 m = m0 + q * 64 + lane;
+                                const bool eq = m < s1 && v[q] == k0;
+                                const u64 em = __ballot(eq);
+                                if (eq)
+                                    P[m] = (unsigned short)(run + (u32)__popcll(em & lane_lt));
+                                run += (u32)__popcll(em);
+                            }
+                        }
+                        placed += run - (s0 + below);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (lane == 0)
                         atomicOr(&uniform_bits[b >> 5], 1u << (b & 31));
                 }
                 __syncthreads();
             }
+            STAMP(11); // long bins (rare)
             if (rem > sb && !(dbg & 1)) {
                 // exact position inside each (small) bin: thread i ranks the key staged at i
                 if (sshift <= 32)
-                    rank_in_bins<NT, ITEMS, u32>(A, H16, uniform_bits, len, sshift, smask, nbig, key, rank);
+                    rank_in_bins<NT, ITEMS, u32>(A, H16, uniform_bits, P, len, sshift, smask, nbig, key, rank);
                 else
-                    rank_in_bins<NT, ITEMS, u64>(A, H16, uniform_bits, len, sshift, smask, nbig, key, rank);
+                    rank_in_bins<NT, ITEMS, u64>(A, H16, uniform_bits, P, len, sshift, smask, nbig, key, rank);
                 __syncthreads();
                 STAMP(5);  // in-bin rank
 #pragma unroll

@@ -78,6 +78,7 @@ struct LevelCounters {  // read back by the host once per level
     u32 max_bits;       // widest split of this level
     u32 n_big;          // unsplit nodes that sort more than LEAF_CAP_SMALL keys (the six-keys-per-thread leaves kernel)
     u32 n_small;        // unsplit nodes that sort at most LEAF_CAP_SMALL keys; the rest are single-key or empty nodes
+    u32 n_over;         // (levels >= 2) nodes over the leaf capacity, counted before the plan
 };
 
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,

@@ -228,7 +228,7 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
 /* ---- instrumentation ------------------------------------------------------------------------
  * Device time in milliseconds (HIP events on the context's stream) of the phases of the most
  * recent dnagpu_count_kmers / dnagpu_count_keys call.  names[i] are static strings. */
-#define DNAGPU_MAX_PHASES 16
+#define DNAGPU_MAX_PHASES 48
 typedef struct dnagpu_phase_times {
     int         n;
     const char *names[DNAGPU_MAX_PHASES];
