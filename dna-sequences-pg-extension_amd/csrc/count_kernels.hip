@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                                                                 u32 *__restrict__ vary)
 {
     __shared__ u32 h[ROW_STRIDE];
-    __shared__ u32 sh_vary;
+    __shared__ u32 sh_vary, sh_eq;
     if (blockIdx.x >= n_chunks)
         return;
     const Chunk ch = chunks[blockIdx.x];
@@ -414,12 +414,19 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
         // child stays in place and resumes at the first varying bit (level_children), terminal if none varies.
         const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + origin;
         const u64 ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];    // the node's first key
-        if (threadIdx.x == 0)
+        // ... and how many keys EQUAL that first key: a node dominated by it (half its keys or more) is split
+        // three ways around it instead (level_children, peel_scatter_kernel).
+        if (threadIdx.x == 0) {
             sh_vary = 0;
+            sh_eq = 0;
+        }
         u64 v = 0;
+        u32 neq = 0;
         for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
             const u64 key = NT_LOAD(&src[i]);
-            v |= key ^ ref;
+            const u64 x = key ^ ref;
+            v |= x;
+            neq += x == 0 ? 1u : 0u;
             atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
         }
         if (vary) {
@@ -427,9 +434,17 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
             const u32 hb = v ? 64u - (u32)__builtin_clzll(v) : 0u;
             if (hb > 0)                                 // (skipped by whole workgroups of identical keys)
                 atomicMax(&sh_vary, hb);
+            const u32 weq = wave_sum(neq);
+            if ((threadIdx.x & 63) == 0 && weq)
+                atomicAdd(&sh_eq, weq);
             __syncthreads();
-            if (threadIdx.x == 0 && sh_vary > 0)
-                atomicMax(&vary[ch.node], sh_vary);
+            if (threadIdx.x == 0) {
+                u32 *st = vary + (size_t)ch.node * NODE_STAT_WORDS;
+                if (sh_vary > 0)
+                    atomicMax(&st[0], sh_vary);
+                if (sh_eq)
+                    atomicAdd(&st[2], sh_eq);
+            }
         }
     }
     __syncthreads();
@@ -515,7 +530,7 @@ __global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slic
 // (NODE_SKIP); its one non-empty child is the node itself, in place, with only the varying low bits left.
 __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_nodes,
                                                              u32 *__restrict__ tot, Node *__restrict__ next,
-                                                             const u32 *__restrict__ vary,
+                                                             u32 *__restrict__ vary,
                                                              const u64 *__restrict__ buf0,
                                                              const u64 *__restrict__ buf1)
 {
@@ -551,13 +566,24 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
     block_scan_inplace<256>(ex, (int)R, wtmp);
     const u32 child_meta = (u32)(rem - bits) | ((nd.meta & NODE_BUF) ^ NODE_BUF) |
                            ((bits == rem) ? NODE_TERMINAL : 0u);
-    const u32 hv = vary ? vary[i] : 64u;
-    const bool stay = nd.len > 0 && hv <= (u32)(rem - bits) && bits < rem;
+    u32 *st = vary ? vary + (size_t)i * NODE_STAT_WORDS : nullptr;
+    const u32 hv = st ? st[0] : 64u;
+    const u32 n_eq = st ? st[2] : 0u;
+    // all keys equal, or half of them (or more) equal to the first key with a different one among them: the
+    // node is split around that key -- {below, the key itself (terminal), above} take the first three child
+    // slots, in key order; the heavy key's copies are not moved again.  Else, all keys in one digit: in place.
+    const bool peel = st && nd.len > 0 && bits >= 2 && bits < rem && hv > 0 && 2ull * n_eq >= nd.len;
+    const bool stay = !peel && nd.len > 0 && hv <= (u32)(rem - bits) && bits < rem;
     u64 ref = 0;
-    if (stay) {
+    if (stay || peel) {
         ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];
-        if (threadIdx.x == 0)
-            nodes[i].meta = nd.meta | NODE_SKIP;
+        if (threadIdx.x == 0) {
+            nodes[i].meta = nd.meta | (peel ? NODE_PEEL : NODE_SKIP);
+            if (peel) {
+                st[3] = 0;                        // cursors of the two moved parts (peel_scatter_kernel)
+                st[4] = 0;
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < ROW_STRIDE / 256; q++) {
@@ -573,6 +599,22 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
                 c.meta = hv | (nd.meta & NODE_BUF) | (hv == 0 ? NODE_TERMINAL : 0u);
                 c.prefix = (ref >> hv) << hv;
             }
+            if (peel) {
+                c.prefix = nd.prefix;             // the moved parts keep every free bit of the node
+                c.meta = (u32)rem | ((nd.meta & NODE_BUF) ^ NODE_BUF);
+                if (d == 0 || d == 2) {           // below / above: sizes known once the keys have moved (peel_fix_kernel)
+                    c.start = nd.start;
+                    c.len = 0;
+                } else if (d == 1) {
+                    c.start = nd.start;
+                    c.len = n_eq;
+                    c.meta = NODE_TERMINAL;
+                    c.prefix = ref;
+                } else {
+                    c.start = nd.start + nd.len;
+                    c.len = 0;
+                }
+            }
             c.child_base = 0;
             c.chunk_base = 0;
             next[nd.child_base + d] = c;
@@ -581,7 +623,7 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
     }
 }
 
-hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *hist, Node *next, const u32 *vary, const u64 *buf0,
+hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *hist, Node *next, u32 *vary, const u64 *buf0,
                                  const u64 *buf1, hipStream_t s)
 {
     // `hist` here is the tot table (same geometry as the hist table); the prefix kernel is launched
@@ -633,7 +675,7 @@ __global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__r
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem || (nd.meta & NODE_SKIP))
+    if (bits == rem || (nd.meta & (NODE_SKIP | NODE_PEEL)))
         return;                                   // terminal split: children carry (key, count) already
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;
@@ -789,7 +831,7 @@ __global__ __launch_bounds__(NTH, 4) void level_scatter_wc_kernel(const Node *__
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem || (nd.meta & NODE_SKIP))
+    if (bits == rem || (nd.meta & (NODE_SKIP | NODE_PEEL)))
         return;                                   // terminal split: nothing moves
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;
@@ -985,7 +1027,7 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
     const Node nd = nodes[ch.node];
     const int bits = (int)nd.split;
     const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem || (nd.meta & NODE_SKIP))
+    if (bits == rem || (nd.meta & (NODE_SKIP | NODE_PEEL)))
         return;                                   // terminal split: nothing moves
     const int shift = rem - bits;
     const u32 R = 1u << bits, dmask = R - 1;
@@ -1132,6 +1174,99 @@ static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, con
     else
         hipLaunchKernelGGL((level_scatter_kernel<false, NT, ITEMS, MINW>), dim3(n_chunks), dim3(NT), SC_SMEM, s,
                            nodes, chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, dbg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// peel_scatter: the chunks of NODE_PEEL nodes (dominated by their first key `ref`).  Keys below ref fill the
+// node's range from its start upwards, keys above it from its end downwards; copies of ref stay behind (their
+// count is the terminal child).  Order inside a part is irrelevant, so a tile takes its two output ranges
+// from the node's cursors with one atomic each; peel_fix_kernel then gives the two children their sizes.
+constexpr int PEEL_THREADS = 1024;
+constexpr int PEEL_ITEMS = 4;
+__global__ __launch_bounds__(PEEL_THREADS) void peel_scatter_kernel(const Node *__restrict__ nodes,
+                                                                    const Chunk *__restrict__ chunks, u32 n_chunks,
+                                                                    u64 *__restrict__ buf0, u64 *__restrict__ buf1,
+                                                                    u32 *__restrict__ stat)
+{
+    __shared__ u32 wt[PEEL_THREADS / 64][2];
+    __shared__ u32 base[2], tsum[2];
+    if (blockIdx.x >= n_chunks)
+        return;
+    const Chunk ch = chunks[blockIdx.x];
+    const Node nd = nodes[ch.node];
+    if (!(nd.meta & NODE_PEEL))
+        return;
+    const u64 *__restrict__ srcb = (nd.meta & NODE_BUF) ? buf1 : buf0;
+    u64 *__restrict__ dst = (nd.meta & NODE_BUF) ? buf0 : buf1;
+    const u64 ref = srcb[nd.start];
+    const u64 *__restrict__ src = srcb + nd.start + ch.off;
+    u32 *st = stat + (size_t)ch.node * NODE_STAT_WORDS;
+    const u32 lt_start = nd.start, gt_end = nd.start + nd.len;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 t0 = 0; t0 < ch.len; t0 += PEEL_THREADS * PEEL_ITEMS) {
+        u64 key[PEEL_ITEMS];
+        u32 nl = 0, ng = 0;
+#pragma unroll
+        for (int j = 0; j < PEEL_ITEMS; j++) {
+            const u32 i = t0 + tid + j * PEEL_THREADS;
+            key[j] = i < ch.len ? NT_LOAD(&src[i]) : ref;     // (past the end: counts as a copy of ref, not moved)
+            nl += key[j] < ref ? 1u : 0u;
+            ng += key[j] > ref ? 1u : 0u;
+        }
+        const u32 il = wave_incl_scan(nl), ig = wave_incl_scan(ng);
+        if (lane == 63) {
+            wt[wave][0] = il;
+            wt[wave][1] = ig;
+        }
+        __syncthreads();
+        if (tid < 2) {                              // thread 0: below, thread 1: above
+            u32 sum = 0;
+            for (int w = 0; w < PEEL_THREADS / 64; w++) {
+                const u32 t = wt[w][tid];
+                wt[w][tid] = sum;
+                sum += t;
+            }
+            base[tid] = sum ? atomicAdd(&st[3 + tid], sum) : 0u;
+            tsum[tid] = sum;
+        }
+        __syncthreads();
+        u32 pl = lt_start + base[0] + wt[wave][0] + il - nl;
+        u32 pg = gt_end - base[1] - tsum[1] + wt[wave][1] + ig - ng;
+#pragma unroll
+        for (int j = 0; j < PEEL_ITEMS; j++) {
+            if (key[j] < ref)
+                dst[pl++] = key[j];
+            else if (key[j] > ref)
+                dst[pg++] = key[j];
+        }
+        __syncthreads();                            // wt / base are rewritten by the next tile
+    }
+}
+
+__global__ __launch_bounds__(256) void peel_fix_kernel(const Node *__restrict__ nodes, u32 n_nodes,
+                                                       Node *__restrict__ next, const u32 *__restrict__ stat)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes)
+        return;
+    const Node nd = nodes[i];
+    if (!(nd.meta & NODE_PEEL))
+        return;
+    const u32 *st = stat + (size_t)i * NODE_STAT_WORDS;
+    next[nd.child_base].len = st[3];
+    next[nd.child_base + 2].start = nd.start + nd.len - st[4];
+    next[nd.child_base + 2].len = st[4];
+}
+
+hipError_t launch_peel_scatter(const Node *nodes, u32 n_nodes, const Chunk *chunks, u32 n_chunks, Node *next, u64 *buf0,
+                               u64 *buf1, u32 *stat, hipStream_t s)
+{
+    if (n_chunks == 0 || n_nodes == 0 || !stat)
+        return hipSuccess;
+    hipLaunchKernelGGL(peel_scatter_kernel, dim3(n_chunks), dim3(PEEL_THREADS), 0, s, nodes, chunks, n_chunks, buf0, buf1,
+                       stat);
+    hipLaunchKernelGGL(peel_fix_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, next, stat);
+    return hipGetLastError();
 }
 
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,

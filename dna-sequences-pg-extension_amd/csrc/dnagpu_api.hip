@@ -975,8 +975,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         // key-source levels: level_hist also finds, per node, how many low key bits vary (see level_children)
         u32 *vary = nullptr;
         if (!src_dna && !(force_bits > 0 && level == 0)) {
-            RC_TRY(ps.alloc(n_nodes, &vary));
-            HIP_TRY(hipMemsetAsync(vary, 0, (size_t)n_nodes * sizeof(u32), st));
+            RC_TRY(ps.alloc((size_t)n_nodes * NODE_STAT_WORDS, &vary));
+            HIP_TRY(hipMemsetAsync(vary, 0, (size_t)n_nodes * NODE_STAT_WORDS * sizeof(u32), st));
         }
         HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, chunks, st));
         prof_mark(ctx, LEVEL_HIST_NAMES[li]);
@@ -1003,6 +1003,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
             HIP_TRY(launch_level_scatter(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                          dna ? dna->n_words : 0, first, k, buf0, buf1, hist, tot,
                                          src_dna ? flt_lo : 0u, src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, hc.max_bits, st));
+            if (vary)                   // nodes dominated by one key: three-way split around it (returns at once if none)
+                HIP_TRY(launch_peel_scatter(cur, n_nodes, chunks, hc.n_chunks, next, buf0, buf1, vary, st));
         }
         ps.free_now(outc);
         ps.free_now(nch);

@@ -62,6 +62,10 @@ struct Node {           // 32 bytes
 constexpr u32 NODE_BUF = 1u << 8;
 constexpr u32 NODE_TERMINAL = 1u << 9;
 constexpr u32 NODE_SKIP = 1u << 10;     // this level only: all keys share the digit, the scatter leaves the node where it is
+constexpr u32 NODE_PEEL = 1u << 11;     // this level only: the node is split three ways around its dominant first key
+// per node and key-source level (level_hist -> level_children -> peel_scatter): varying low bits, keys equal
+// to the node's first key, cursors of the two moved parts of a peeled node
+constexpr int NODE_STAT_WORDS = 8;
 
 struct Chunk {          // 16 bytes: a contiguous piece of one node, the unit of work of a level
     u32 node;
@@ -97,10 +101,13 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
                                u32 *hist, u32 *tot, hipStream_t s);
 // per node: leaf -> copied to the next list; split -> totals scanned over digits, children appended
 // in digit (= key) order, tot row overwritten with each digit's absolute base
-// vary (may be null): per node, the number of low key bits that vary inside it, as level_hist found (key-source
-// levels); a node whose keys all share this level's digit is flagged NODE_SKIP and stays where it is
-hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *tot, Node *next, const u32 *vary, const u64 *buf0,
+// vary (may be null): per node NODE_STAT_WORDS words -- the number of low key bits that vary inside it, keys below /
+// equal to its first key -- as level_hist found (key-source levels); a node whose keys all share this level's digit is flagged NODE_SKIP and stays where it is
+hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *tot, Node *next, u32 *vary, const u64 *buf0,
                                  const u64 *buf1, hipStream_t s);
+// the chunks of nodes that level_children flagged NODE_PEEL (stat = the NODE_STAT_WORDS-per-node table)
+hipError_t launch_peel_scatter(const Node *nodes, u32 n_nodes, const Chunk *chunks, u32 n_chunks, Node *next, u64 *buf0,
+                               u64 *buf1, u32 *stat, hipStream_t s);
 hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                                 const u64 *words, u64 n_words, u64 first, int k, u64 *buf0, u64 *buf1,
                                 const u32 *hist, const u32 *tot, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 max_bits,
