@@ -1460,25 +1460,6 @@ __device__ __forceinline__ bool leaf_in_class(const Node &nd, bool big_class)
 
 // The first leaf of the class at or behind `from`, in steps of `step` (n_leaves if none): the 64 lanes
 // test 64 candidates per round (a scalar walk paid one memory latency per skipped leaf).
-__device__ __forceinline__ u32 next_leaf_in_class(const Node *__restrict__ leaves, u32 n_leaves, u32 from, u32 step,
-                                                  bool big_class)
-{
-    const u32 lane = threadIdx.x & 63;
-    for (u64 base = from; base < n_leaves; base += (u64)64 * step) {
-        const u64 cand = base + (u64)lane * step;
-        bool ok = false;
-        if (cand < n_leaves) {
-            Node nd;
-            nd.len = leaves[cand].len;
-            nd.meta = leaves[cand].meta;
-            ok = leaf_in_class(nd, big_class);
-        }
-        const u64 m = __ballot(ok);
-        if (m)
-            return (u32)(base + (u64)__builtin_ctzll(m) * step);
-    }
-    return n_leaves;
-}
 
 // CAP = 4096 (four keys per thread at 1024 threads) or 6144 (six): the host launches one kernel per
 // class present; each skips the other class's leaves.  Bigger leaves let the level above split on
@@ -1492,9 +1473,11 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
                                                           unsigned long long *__restrict__ cursor,
                                                           u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
                                                           u64 *__restrict__ out_keys,
-                                                          u32 *__restrict__ out_counts, int dbg)
+                                                          u32 *__restrict__ out_counts, int dbg,
+                                                          const u32 *__restrict__ list, u32 n_list)
 {
-    constexpr bool BIG = CAP > LEAF_CAP_SMALL;
+    // MIXED: the node list also holds leaves of the other class or nodes that do not sort; `list` then
+    // holds the indices of this launch's leaves (class_list_kernel) and workgroup b takes entries b, b + grid, ...
     constexpr int ITEMS = CAP / NT;            // keys per thread
     constexpr int BINS = 8192;                 // counting-sort bins (mean occupancy 0.35-0.7), 16-bit counters:
     constexpr int WPT = BINS / 2 / NT;         // two bins per LDS word, WPT consecutive words per thread in the scan
@@ -1523,11 +1506,17 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     __shared__ u32 uniform_bits[BINS / 32];   // bit b: bin b is long and a wave has placed its heavy members (P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 lq = blockIdx.x;                       // MIXED: position in `list`
     u32 li = blockIdx.x;
     if (MIXED)
-        li = next_leaf_in_class(leaves, n_leaves, li, gridDim.x, BIG);
+        li = lq < n_list ? list[lq] : n_leaves;
     if (li >= n_leaves)
         return;
+    u32 ln_list = n_leaves;                    // MIXED: the leaf after this one, fetched one iteration ahead
+    if (MIXED) {
+        lq += gridDim.x;
+        ln_list = lq < n_list ? list[lq] : n_leaves;
+    }
     Node nd = leaves[li];
     u64 key[ITEMS];
     if (nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL)) {
@@ -1547,8 +1536,11 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     STAMP_DECL
     for (;;) {
         u32 ln = li + gridDim.x;
-        if (MIXED)
-            ln = next_leaf_in_class(leaves, n_leaves, ln < n_leaves ? ln : n_leaves, gridDim.x, BIG);
+        if (MIXED) {
+            ln = ln_list;
+            lq += gridDim.x;
+            ln_list = lq < n_list ? list[lq] : n_leaves;
+        }
         const bool has_next = ln < n_leaves;
         const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
         __syncthreads();                           // A/H of the previous leaf are dead
@@ -1904,6 +1896,23 @@ __global__ __launch_bounds__(256) void single_flags_kernel(const Node *__restric
     flags[i] = (!sorts && nd.len > 0) ? 1u : 0u;
 }
 
+// The leaves of one class among a mixed node list: flags -> exclusive scan -> compact index list.
+__global__ __launch_bounds__(256) void class_flags_kernel(const Node *__restrict__ leaves, u32 n_leaves, int big_class,
+                                                          u32 *__restrict__ flags)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_leaves)
+        flags[i] = leaf_in_class(leaves[i], big_class != 0) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void class_list_kernel(const Node *__restrict__ leaves, u32 n_leaves, int big_class,
+                                                         const u32 *__restrict__ pre, u32 *__restrict__ list)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_leaves && leaf_in_class(leaves[i], big_class != 0))
+        list[pre[i]] = i;
+}
+
 __global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                            const u32 *__restrict__ pre, const u32 *__restrict__ total,
                                                            unsigned long long *__restrict__ cursor,
@@ -1930,7 +1939,7 @@ __global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restric
 
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, hipStream_t s)
+                         u32 *scan_tmp, u32 *list, hipStream_t s)
 {
     if (n_leaves == 0)
         return hipSuccess;
@@ -1956,16 +1965,26 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_bi
                            seg_off, seg_cnt, out_keys, out_counts);
     }
     const bool mixed_small = n_small < n_leaves, mixed_big = n_big < n_leaves;
+    // (flags / scan_tmp / list are reused by the second class: same stream, the first launch is done with them)
 #define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_, MIXED_)                                                                        \
     do {                                                                                                              \
-        if (MIXED_)                                                                                                   \
-            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),   \
+        if (MIXED_) {                                                                                                 \
+            const u32 n_cls = (CAP_) > LEAF_CAP_SMALL ? n_big : n_small;                                              \
+            const u32 g = (n_leaves + 255) / 256;                                                                     \
+            hipLaunchKernelGGL(class_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves,                        \
+                               (CAP_) > LEAF_CAP_SMALL ? 1 : 0, flags);                                               \
+            hipError_t e2 = launch_scan_u32(flags, flags, n_leaves, scan_tmp, flags + n_leaves, s);                   \
+            if (e2 != hipSuccess)                                                                                     \
+                return e2;                                                                                            \
+            hipLaunchKernelGGL(class_list_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves,                         \
+                               (CAP_) > LEAF_CAP_SMALL ? 1 : 0, flags, list);                                         \
+            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true>), dim3(leaves_grid(n_cls, PER_CU_ * mult)),     \
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
-                               out_counts, dbg);                                                                      \
-        else                                                                                                          \
+                               out_counts, dbg, list, n_cls);                                                         \
+        } else                                                                                                        \
             hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, false>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),  \
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
-                               out_counts, dbg);                                                                      \
+                               out_counts, dbg, (const u32 *)nullptr, 0u);                                            \
     } while (0)
     if (n_small > 0) {                                   // leaves of at most LEAF_CAP_SMALL keys
         if (variant == 2)

@@ -1131,10 +1131,12 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         if (rc == DNAGPU_OK) rc = ps.alloc(tr.n_nodes, &seg_cnt);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
-        u32 *flags = nullptr, *scan_tmp = nullptr;
-        if (rc == DNAGPU_OK && tr.n_small + tr.n_big < tr.n_nodes) {     // single-key / empty nodes: emitted in bulk
+        u32 *flags = nullptr, *scan_tmp = nullptr, *cls_list = nullptr;
+        if (rc == DNAGPU_OK && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes) {
+            // a mixed node list: single-key / empty nodes are emitted in bulk, each leaf class gets an index list
             rc = ps.alloc((size_t)tr.n_nodes + 1, &flags);
             if (rc == DNAGPU_OK) rc = ps.alloc((size_t)scan_tmp_words(tr.n_nodes), &scan_tmp);
+            if (rc == DNAGPU_OK) rc = ps.alloc((size_t)tr.n_nodes, &cls_list);
         }
         hipError_t e = hipSuccess;
         u64 total_groups = 0;
@@ -1143,7 +1145,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
                 e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt,
-                                  ok, oc, flags, scan_tmp, ctx->stream);
+                                  ok, oc, flags, scan_tmp, cls_list, ctx->stream);
             prof_mark(ctx, "end");
             if (e == hipSuccess)
                 e = hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);

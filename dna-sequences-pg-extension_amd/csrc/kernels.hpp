@@ -115,10 +115,11 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
 // n_small / n_big: leaves per sorting class; the other leaves hold one distinct key (or none) and are emitted
-// in bulk, for which flags / scan_tmp (n_leaves + 1 and scan_tmp_words(n_leaves) u32) are needed when there are any
+// in bulk; flags / scan_tmp / list (n_leaves + 1, scan_tmp_words(n_leaves) and n_leaves u32) are needed unless all
+// nodes are sorting leaves of one class
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, hipStream_t s);
+                         u32 *scan_tmp, u32 *list, hipStream_t s);
 // dense count of short k-mers straight from the packed sequence (2k = bits <= dense_max_bits()): table must hold
 // 2^bits u32 counters, out_keys/out_counts 2^bits entries; *n_out = distinct keys; results ascending
 int dense_max_bits();
