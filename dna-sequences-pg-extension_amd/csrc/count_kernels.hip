@@ -373,10 +373,10 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                                                                 const u64 *__restrict__ buf0,
                                                                 const u64 *__restrict__ buf1,
                                                                 u32 *__restrict__ hist, DigitFilter flt,
-                                                                u32 *__restrict__ vary)
+                                                                u32 *__restrict__ vary, int multi_ref)
 {
     __shared__ u32 h[ROW_STRIDE];
-    __shared__ u32 sh_vary, sh_eq;
+    __shared__ u32 sh_vary, sh_eq, sh_eq1, sh_eq2;
     if (blockIdx.x >= n_chunks)
         return;
     const Chunk ch = chunks[blockIdx.x];
@@ -416,18 +416,36 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
         const u64 ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];    // the node's first key
         // ... and how many keys EQUAL that first key: a node dominated by it (half its keys or more) is split
         // three ways around it instead (level_children, peel_scatter_kernel).
+        // Deep levels (multi_ref: every node there is oversize because of skew) try three candidates -- the
+        // node's first, middle and last key -- so that a heavy key is missed only if it is none of them.
         if (threadIdx.x == 0) {
             sh_vary = 0;
             sh_eq = 0;
+            sh_eq1 = 0;
+            sh_eq2 = 0;
         }
         u64 v = 0;
-        u32 neq = 0;
-        for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
-            const u64 key = NT_LOAD(&src[i]);
-            const u64 x = key ^ ref;
-            v |= x;
-            neq += x == 0 ? 1u : 0u;
-            atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
+        u32 neq = 0, neq1 = 0, neq2 = 0;
+        if (multi_ref) {
+            const u64 *__restrict__ nb = (nd.meta & NODE_BUF) ? buf1 : buf0;
+            const u64 ref1 = nb[nd.start + nd.len / 2], ref2 = nb[nd.start + nd.len - 1];
+            for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
+                const u64 key = NT_LOAD(&src[i]);
+                const u64 x = key ^ ref;
+                v |= x;
+                neq += x == 0 ? 1u : 0u;
+                neq1 += key == ref1 ? 1u : 0u;
+                neq2 += key == ref2 ? 1u : 0u;
+                atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
+            }
+        } else {
+            for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
+                const u64 key = NT_LOAD(&src[i]);
+                const u64 x = key ^ ref;
+                v |= x;
+                neq += x == 0 ? 1u : 0u;
+                atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
+            }
         }
         if (vary) {
             __syncthreads();
@@ -437,6 +455,15 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
             const u32 weq = wave_sum(neq);
             if ((threadIdx.x & 63) == 0 && weq)
                 atomicAdd(&sh_eq, weq);
+            if (multi_ref) {
+                const u32 weq1 = wave_sum(neq1), weq2 = wave_sum(neq2);
+                if ((threadIdx.x & 63) == 0) {
+                    if (weq1)
+                        atomicAdd(&sh_eq1, weq1);
+                    if (weq2)
+                        atomicAdd(&sh_eq2, weq2);
+                }
+            }
             __syncthreads();
             if (threadIdx.x == 0) {
                 u32 *st = vary + (size_t)ch.node * NODE_STAT_WORDS;
@@ -444,6 +471,10 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                     atomicMax(&st[0], sh_vary);
                 if (sh_eq)
                     atomicAdd(&st[2], sh_eq);
+                if (sh_eq1)
+                    atomicAdd(&st[5], sh_eq1);
+                if (sh_eq2)
+                    atomicAdd(&st[6], sh_eq2);
             }
         }
     }
@@ -455,17 +486,18 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
 
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, hipStream_t s)
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, int multi_ref,
+                             hipStream_t s)
 {
     const DigitFilter flt{flt_lo, flt_span, flt_tb};
     if (n_chunks == 0)
         return hipSuccess;
     if (src_dna)
         hipLaunchKernelGGL(level_hist_kernel<true>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, (u32 *)nullptr);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, (u32 *)nullptr, 0);
     else
         hipLaunchKernelGGL(level_hist_kernel<false>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, vary);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, vary, multi_ref);
     return hipGetLastError();
 }
 
@@ -568,7 +600,16 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
                            ((bits == rem) ? NODE_TERMINAL : 0u);
     u32 *st = vary ? vary + (size_t)i * NODE_STAT_WORDS : nullptr;
     const u32 hv = st ? st[0] : 64u;
-    const u32 n_eq = st ? st[2] : 0u;
+    u32 n_eq = st ? st[2] : 0u;
+    u32 ridx = 0;                                 // the candidate with most copies (deep levels count three)
+    if (st && st[5] > n_eq) {
+        n_eq = st[5];
+        ridx = 1;
+    }
+    if (st && st[6] > n_eq) {
+        n_eq = st[6];
+        ridx = 2;
+    }
     // all keys equal, or half of them (or more) equal to the first key with a different one among them: the
     // node is split around that key -- {below, the key itself (terminal), above} take the first three child
     // slots, in key order; the heavy key's copies are not moved again.  Else, all keys in one digit: in place.
@@ -576,12 +617,14 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
     const bool stay = !peel && nd.len > 0 && hv <= (u32)(rem - bits) && bits < rem;
     u64 ref = 0;
     if (stay || peel) {
-        ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start];
+        const u32 roff = !peel || ridx == 0 ? 0u : (ridx == 1 ? nd.len / 2 : nd.len - 1);
+        ref = ((nd.meta & NODE_BUF) ? buf1 : buf0)[nd.start + roff];
         if (threadIdx.x == 0) {
             nodes[i].meta = nd.meta | (peel ? NODE_PEEL : NODE_SKIP);
             if (peel) {
                 st[3] = 0;                        // cursors of the two moved parts (peel_scatter_kernel)
                 st[4] = 0;
+                st[7] = roff;                     // where the pivot key is
             }
         }
     }
@@ -1198,9 +1241,9 @@ __global__ __launch_bounds__(PEEL_THREADS) void peel_scatter_kernel(const Node *
         return;
     const u64 *__restrict__ srcb = (nd.meta & NODE_BUF) ? buf1 : buf0;
     u64 *__restrict__ dst = (nd.meta & NODE_BUF) ? buf0 : buf1;
-    const u64 ref = srcb[nd.start];
-    const u64 *__restrict__ src = srcb + nd.start + ch.off;
     u32 *st = stat + (size_t)ch.node * NODE_STAT_WORDS;
+    const u64 ref = srcb[nd.start + st[7]];
+    const u64 *__restrict__ src = srcb + nd.start + ch.off;
     const u32 lt_start = nd.start, gt_end = nd.start + nd.len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (u32 t0 = 0; t0 < ch.len; t0 += PEEL_THREADS * PEEL_ITEMS) {

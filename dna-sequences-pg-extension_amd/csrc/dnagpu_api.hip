@@ -982,7 +982,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         prof_mark(ctx, LEVEL_HIST_NAMES[li]);
         HIP_TRY(launch_level_hist(cur, chunks, hc.n_chunks, src_dna, dna ? dna->words : nullptr,
                                   dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
-                                  src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, vary, st));
+                                  src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, vary, level >= 2 ? 1 : 0, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
         HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st));
         HIP_TRY(launch_level_children(cur, n_nodes, tot, next, vary, buf0, buf1, st));

@@ -94,7 +94,8 @@ hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, con
 // aligned power-of-two range and only the digit's top tb bits need testing)
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
-                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, hipStream_t s);
+                             const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, int multi_ref,
+                             hipStream_t s);
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
