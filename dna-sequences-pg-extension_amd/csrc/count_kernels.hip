@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
     const bool sorts = bits == 0 && nd.len > 0 && rem > 0 && !(nd.meta & NODE_TERMINAL);
     if (sorts && nd.len > (u32)LEAF_CAP_SMALL)
         atomicAdd(&ctr->n_big, 1u);
-    if (sorts && nd.len <= (u32)LEAF_CAP_SMALL)
+    if (sorts && nd.len <= (u32)LEAF_CAP_SMALL && nd.len > (u32)LEAF_CAP_TINY)
         atomicAdd(&ctr->n_small, 1u);
+    if (sorts && nd.len <= (u32)LEAF_CAP_TINY)
+        atomicAdd(&ctr->n_tiny, 1u);
     nodes[i].split = (u32)bits;
     outc[i] = bits ? (1u << bits) : 1u;
     nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
@@ -1495,10 +1497,12 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short 
 }
 
 // A leaf that sorts (not a single-key node) belongs to the class of the kernel whose capacity it needs.
-__device__ __forceinline__ bool leaf_in_class(const Node &nd, bool big_class)
+// (classes: 0 = up to LEAF_CAP_TINY keys, 1 = up to LEAF_CAP_SMALL, 2 = up to LEAF_CAP)
+__device__ __forceinline__ bool leaf_in_class(const Node &nd, int cls)
 {
     const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
-    return sorts && (nd.len > (u32)LEAF_CAP_SMALL) == big_class;   // (single-key and empty nodes: emit_singles_kernel)
+    const int c = nd.len > (u32)LEAF_CAP_SMALL ? 2 : (nd.len > (u32)LEAF_CAP_TINY ? 1 : 0);
+    return sorts && c == cls;                      // (single-key and empty nodes: emit_singles_kernel)
 }
 
 // The first leaf of the class at or behind `from`, in steps of `step` (n_leaves if none): the 64 lanes
@@ -1509,7 +1513,7 @@ __device__ __forceinline__ bool leaf_in_class(const Node &nd, bool big_class)
 // half as many digits (15 % cheaper per key), smaller ones cost less per key here.
 // MIXED: the leaf list holds both classes and this kernel skips the other one's leaves (the search
 // loop costs registers, so launches over a single-class list use the MIXED = false instantiation).
-template <int NT, int MINW, int CAP, bool MIXED>
+template <int NT, int MINW, int CAP, bool MIXED, int SB = 13>
 __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                           const u64 *__restrict__ buf0,
                                                           const u64 *__restrict__ buf1,
@@ -1522,9 +1526,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     // MIXED: the node list also holds leaves of the other class or nodes that do not sort; `list` then
     // holds the indices of this launch's leaves (class_list_kernel) and workgroup b takes entries b, b + grid, ...
     constexpr int ITEMS = CAP / NT;            // keys per thread
-    constexpr int BINS = 8192;                 // counting-sort bins (mean occupancy 0.35-0.7), 16-bit counters:
+    constexpr int BINS = 1 << SB;              // counting-sort bins (8192: mean occupancy 0.35-0.7), 16-bit counters:
     constexpr int WPT = BINS / 2 / NT;         // two bins per LDS word, WPT consecutive words per thread in the scan
-    constexpr int SB = 13;
     constexpr int WAVES = NT / 64;
     constexpr int ROWS = ITEMS * WAVES;        // 64-position rows of the staged leaf
     constexpr u32 BIG_BIN = 24;
@@ -1945,14 +1948,14 @@ __global__ __launch_bounds__(256) void class_flags_kernel(const Node *__restrict
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_leaves)
-        flags[i] = leaf_in_class(leaves[i], big_class != 0) ? 1u : 0u;
+        flags[i] = leaf_in_class(leaves[i], big_class) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void class_list_kernel(const Node *__restrict__ leaves, u32 n_leaves, int big_class,
                                                          const u32 *__restrict__ pre, u32 *__restrict__ list)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_leaves && leaf_in_class(leaves[i], big_class != 0))
+    if (i < n_leaves && leaf_in_class(leaves[i], big_class))
         list[pre[i]] = i;
 }
 
@@ -1980,7 +1983,8 @@ __global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restric
     }
 }
 
-hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0,
+                         const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
                          u32 *scan_tmp, u32 *list, hipStream_t s)
 {
@@ -1998,7 +2002,7 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_bi
             mult = 1;
     }
     unsigned long long *cur = reinterpret_cast<unsigned long long *>(cursor);
-    if (n_small + n_big < n_leaves) {                    // single-key and empty nodes
+    if (n_tiny + n_small + n_big < n_leaves) {           // single-key and empty nodes
         const u32 g = (n_leaves + 255) / 256;
         hipLaunchKernelGGL(single_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, flags);
         hipError_t e = launch_scan_u32(flags, flags, n_leaves, scan_tmp, flags + n_leaves, s);   // (flags holds n_leaves + 1)
@@ -2007,42 +2011,47 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_bi
         hipLaunchKernelGGL(emit_singles_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, flags, flags + n_leaves, cur,
                            seg_off, seg_cnt, out_keys, out_counts);
     }
-    const bool mixed_small = n_small < n_leaves, mixed_big = n_big < n_leaves;
+#ifdef DNAGPU_STAMPS
+#define LEAVES_STAMPS(name) stamps_report("leaves " name, 0, s)
+#else
+#define LEAVES_STAMPS(name)
+#endif
+    const bool mixed_tiny = n_tiny < n_leaves, mixed_small = n_small < n_leaves, mixed_big = n_big < n_leaves;
     // (flags / scan_tmp / list are reused by the second class: same stream, the first launch is done with them)
-#define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_, MIXED_)                                                                        \
+#define LAUNCH_LEAVES(NT_, MINW_, CAP_, PER_CU_, MIXED_, SB_)                                                                   \
     do {                                                                                                              \
         if (MIXED_) {                                                                                                 \
-            const u32 n_cls = (CAP_) > LEAF_CAP_SMALL ? n_big : n_small;                                              \
+            const int cls = (CAP_) > LEAF_CAP_SMALL ? 2 : ((CAP_) > LEAF_CAP_TINY ? 1 : 0);                           \
+            const u32 n_cls = cls == 2 ? n_big : (cls == 1 ? n_small : n_tiny);                                       \
             const u32 g = (n_leaves + 255) / 256;                                                                     \
-            hipLaunchKernelGGL(class_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves,                        \
-                               (CAP_) > LEAF_CAP_SMALL ? 1 : 0, flags);                                               \
+            hipLaunchKernelGGL(class_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, cls, flags);           \
             hipError_t e2 = launch_scan_u32(flags, flags, n_leaves, scan_tmp, flags + n_leaves, s);                   \
             if (e2 != hipSuccess)                                                                                     \
                 return e2;                                                                                            \
-            hipLaunchKernelGGL(class_list_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves,                         \
-                               (CAP_) > LEAF_CAP_SMALL ? 1 : 0, flags, list);                                         \
-            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true>), dim3(leaves_grid(n_cls, PER_CU_ * mult)),     \
+            hipLaunchKernelGGL(class_list_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, cls, flags, list);      \
+            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, true, SB_>), dim3(leaves_grid(n_cls, PER_CU_ * mult)), \
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
                                out_counts, dbg, list, n_cls);                                                         \
         } else                                                                                                        \
-            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, false>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)),  \
+            hipLaunchKernelGGL((leaves_kernel<NT_, MINW_, CAP_, false, SB_>), dim3(leaves_grid(n_leaves, PER_CU_ * mult)), \
                                dim3(NT_), 0, s, leaves, n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys,        \
                                out_counts, dbg, (const u32 *)nullptr, 0u);                                            \
+        LEAVES_STAMPS(#CAP_);                                                                                         \
     } while (0)
+    if (n_tiny > 0)                                      // leaves of at most LEAF_CAP_TINY keys: 256-thread workgroups,
+        LAUNCH_LEAVES(256, 8, LEAF_CAP_TINY, 8, mixed_tiny, 11);   // eight per CU, 2048 bins (what skew leaves behind)
     if (n_small > 0) {                                   // leaves of at most LEAF_CAP_SMALL keys
         if (variant == 2)
-            LAUNCH_LEAVES(1024, 4, LEAF_CAP_SMALL, 1, mixed_small);
+            LAUNCH_LEAVES(1024, 4, LEAF_CAP_SMALL, 1, mixed_small, 13);
         else if (variant == 3)
-            LAUNCH_LEAVES(512, 4, LEAF_CAP_SMALL, 2, mixed_small);
+            LAUNCH_LEAVES(512, 4, LEAF_CAP_SMALL, 2, mixed_small, 13);
         else
-            LAUNCH_LEAVES(1024, 8, LEAF_CAP_SMALL, 2, mixed_small);
+            LAUNCH_LEAVES(1024, 8, LEAF_CAP_SMALL, 2, mixed_small, 13);
     }
     if (n_big > 0)                                       // leaves of up to LEAF_CAP keys
-        LAUNCH_LEAVES(1024, 8, LEAF_CAP, 2, mixed_big);
+        LAUNCH_LEAVES(1024, 8, LEAF_CAP, 2, mixed_big, 13);
 #undef LAUNCH_LEAVES
-#ifdef DNAGPU_STAMPS
-    stamps_report("leaves", 0, s);
-#endif
+#undef LEAVES_STAMPS
     return hipGetLastError();
 }
 

@@ -891,7 +891,8 @@ struct TreeResult {
     Node *nodes;      // final node list (leaves, or the children of a forced level)
     u32 n_nodes;
     u32 n_big;        // leaves that sort more than LEAF_CAP_SMALL keys among them
-    u32 n_small;      // leaves that sort at most LEAF_CAP_SMALL keys (the rest: single-key or empty nodes)
+    u32 n_small;      // leaves that sort up to LEAF_CAP_SMALL keys
+    u32 n_tiny;       // leaves that sort at most LEAF_CAP_TINY keys (the rest: single-key or empty nodes)
     u64 n_keys;       // keys in the tree (== n unless an owner filter dropped some at the dna root)
     u64 *buf0;
     u64 *buf1;        // may be null if never needed
@@ -927,7 +928,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     RC_TRY(ps.alloc(1, &cur));
     HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
-    u32 n_nodes = 1, n_big = 0, n_small = 0;
+    u32 n_nodes = 1, n_big = 0, n_small = 0, n_tiny = 0;
 
     static u64 chunk_target = 0;                 // chunks per level (work units of the hist/scatter kernels)
     if (chunk_target == 0) {
@@ -959,6 +960,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         if (hc.n_split == 0) {
             n_big = hc.n_big;                    // every node of the final list was planned (and counted) here
             n_small = hc.n_small;
+            n_tiny = hc.n_tiny;
             ps.free_now(outc);
             ps.free_now(nch);
             ps.free_now(scan_tmp);
@@ -1026,6 +1028,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     res->n_nodes = n_nodes;
     res->n_big = n_big;
     res->n_small = n_small;
+    res->n_tiny = n_tiny;
     res->n_keys = n_keys;
     res->buf0 = buf0;
     res->buf1 = buf1;
@@ -1132,7 +1135,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
         u32 *flags = nullptr, *scan_tmp = nullptr, *cls_list = nullptr;
-        if (rc == DNAGPU_OK && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes) {
+        if (rc == DNAGPU_OK && tr.n_tiny != tr.n_nodes && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes) {
             // a mixed node list: single-key / empty nodes are emitted in bulk, each leaf class gets an index list
             rc = ps.alloc((size_t)tr.n_nodes + 1, &flags);
             if (rc == DNAGPU_OK) rc = ps.alloc((size_t)scan_tmp_words(tr.n_nodes), &scan_tmp);
@@ -1144,7 +1147,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             prof_mark(ctx, "leaves");
             e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
-                e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt,
+                e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt,
                                   ok, oc, flags, scan_tmp, cls_list, ctx->stream);
             prof_mark(ctx, "end");
             if (e == hipSuccess)

@@ -45,6 +45,7 @@ hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total,
 // next most significant bits; leaves (<= LEAF_CAP keys, or no bits left) are sorted and run-length
 // encoded in LDS, in key order, with a chained scan giving each leaf its output offset.
 constexpr int LEAF_CAP = 6144;        // max keys a leaf workgroup sorts in LDS (48 KB of keys, six per thread)
+constexpr int LEAF_CAP_TINY = 1024;   // leaves up to here take 256-thread workgroups (eight per CU)
 constexpr int LEAF_CAP_SMALL = 4096;  // leaves up to here take the four-keys-per-thread kernel
 constexpr int LEAF_TARGET = 5800;     // planned leaf size: a split aims at means in (2900, 5800]; a leaf that still exceeds LEAF_CAP is halved by one more level
 constexpr int MAX_SPLIT_BITS = 10;    // widest digit of one level (1024 children)
@@ -81,7 +82,8 @@ struct LevelCounters {  // read back by the host once per level
     u32 n_scatter;      // of which non-terminal (their keys move)
     u32 max_bits;       // widest split of this level
     u32 n_big;          // unsplit nodes that sort more than LEAF_CAP_SMALL keys (the six-keys-per-thread leaves kernel)
-    u32 n_small;        // unsplit nodes that sort at most LEAF_CAP_SMALL keys; the rest are single-key or empty nodes
+    u32 n_small;        // unsplit nodes that sort LEAF_CAP_TINY < keys <= LEAF_CAP_SMALL
+    u32 n_tiny;         // unsplit nodes that sort at most LEAF_CAP_TINY keys; the rest are single-key or empty nodes
     u32 n_over;         // (levels >= 2) nodes over the leaf capacity, counted before the plan
 };
 
@@ -115,10 +117,10 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
                                 hipStream_t s);
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
-// n_small / n_big: leaves per sorting class; the other leaves hold one distinct key (or none) and are emitted
+// n_tiny / n_small / n_big: leaves per sorting class; the other leaves hold one distinct key (or none) and are emitted
 // in bulk; flags / scan_tmp / list (n_leaves + 1, scan_tmp_words(n_leaves) and n_leaves u32) are needed unless all
 // nodes are sorting leaves of one class
-hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
+hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
                          u32 *scan_tmp, u32 *list, hipStream_t s);
 // dense count of short k-mers straight from the packed sequence (2k = bits <= dense_max_bits()): table must hold
