@@ -1431,7 +1431,9 @@ __device__ __forceinline__ void rank_in_bins(const u64 *A, const unsigned short 
         const u32 b = (u32)(key[j] >> sshift) & smask;
         const u32 l = H[b], h = H[b + 1];
         lo[j] = l;
-        size[j] = h - l;
+        // (slots past the end of the leaf rank nothing: they hold a copy of the last key, and if that is a
+        // heavy one its whole bin would be walked for nothing -- 955 us for a leaf of 5000 equal keys)
+        size[j] = (u32)(tid + j * NT) < len ? h - l : 0u;
     }
     if (nbig > 0) {                                 // rare: the members of a long bin that a wave has placed already
 #pragma unroll
