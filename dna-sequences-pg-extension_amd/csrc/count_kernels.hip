@@ -1507,14 +1507,11 @@ __device__ __forceinline__ bool leaf_in_class(const Node &nd, int cls)
     return sorts && c == cls;                      // (single-key and empty nodes: emit_singles_kernel)
 }
 
-// The first leaf of the class at or behind `from`, in steps of `step` (n_leaves if none): the 64 lanes
-// test 64 candidates per round (a scalar walk paid one memory latency per skipped leaf).
-
-// CAP = 4096 (four keys per thread at 1024 threads) or 6144 (six): the host launches one kernel per
-// class present; each skips the other class's leaves.  Bigger leaves let the level above split on
-// half as many digits (15 % cheaper per key), smaller ones cost less per key here.
-// MIXED: the leaf list holds both classes and this kernel skips the other one's leaves (the search
-// loop costs registers, so launches over a single-class list use the MIXED = false instantiation).
+// CAP = 4096 (four keys per thread at 1024 threads), 6144 (six) or 1024 (four at 256 threads, SB = 11): the
+// host launches one kernel per class present.  Bigger leaves let the level above split on half as many
+// digits (15 % cheaper per key), smaller ones cost less per key here.
+// MIXED: the node list also holds other classes' leaves or nodes that do not sort; the launch then walks the
+// index list of its class (launches over a single-class list use the MIXED = false instantiation).
 template <int NT, int MINW, int CAP, bool MIXED, int SB = 13>
 __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                           const u64 *__restrict__ buf0,
