@@ -375,7 +375,8 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                                                                 const u64 *__restrict__ buf0,
                                                                 const u64 *__restrict__ buf1,
                                                                 u32 *__restrict__ hist, DigitFilter flt,
-                                                                u32 *__restrict__ vary, int multi_ref)
+                                                                u32 *__restrict__ vary_all, int multi_ref,
+                                                                u32 stat_min_len)
 {
     __shared__ u32 h[ROW_STRIDE];
     __shared__ u32 sh_vary, sh_eq, sh_eq1, sh_eq2;
@@ -386,6 +387,9 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
     const int bits = (int)nd.split;
     const int shift = (int)(nd.meta & 0xff) - bits;
     const u32 R = 1u << bits, dmask = R - 1;
+    // node statistics (below) only for nodes of at least stat_min_len keys: at level 1 that is "far above
+    // the mean" -- nothing in uniform data, whose histogram then costs what it did without them
+    u32 *__restrict__ vary = nd.len >= stat_min_len ? vary_all : nullptr;
     for (u32 d = threadIdx.x; d < R; d += SC_THREADS)
         h[d] = 0;
     __syncthreads();
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                 neq2 += key == ref2 ? 1u : 0u;
                 atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
             }
-        } else {
+        } else if (vary) {
             for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS) {
                 const u64 key = NT_LOAD(&src[i]);
                 const u64 x = key ^ ref;
@@ -448,6 +452,9 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
                 neq += x == 0 ? 1u : 0u;
                 atomicAdd(&h[(u32)(key >> shift) & dmask], 1u);
             }
+        } else {
+            for (u32 i = threadIdx.x; i < ch.len; i += SC_THREADS)
+                atomicAdd(&h[(u32)(NT_LOAD(&src[i]) >> shift) & dmask], 1u);
         }
         if (vary) {
             __syncthreads();
@@ -489,17 +496,17 @@ __global__ __launch_bounds__(SC_THREADS) void level_hist_kernel(const Node *__re
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
                              const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, int multi_ref,
-                             hipStream_t s)
+                             u32 stat_min_len, hipStream_t s)
 {
     const DigitFilter flt{flt_lo, flt_span, flt_tb};
     if (n_chunks == 0)
         return hipSuccess;
     if (src_dna)
         hipLaunchKernelGGL(level_hist_kernel<true>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, (u32 *)nullptr, 0);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, (u32 *)nullptr, 0, 0u);
     else
         hipLaunchKernelGGL(level_hist_kernel<false>, dim3(n_chunks), dim3(SC_THREADS), 0, s, nodes, chunks,
-                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, vary, multi_ref);
+                           n_chunks, words, n_words, first, kmer_mask(k), buf0, buf1, hist, flt, vary, multi_ref, stat_min_len);
     return hipGetLastError();
 }
 
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
                                                              u32 *__restrict__ tot, Node *__restrict__ next,
                                                              u32 *__restrict__ vary,
                                                              const u64 *__restrict__ buf0,
-                                                             const u64 *__restrict__ buf1)
+                                                             const u64 *__restrict__ buf1, u32 stat_min_len)
 {
     __shared__ u32 ex[ROW_STRIDE];
     __shared__ u32 wtmp[4];
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
     block_scan_inplace<256>(ex, (int)R, wtmp);
     const u32 child_meta = (u32)(rem - bits) | ((nd.meta & NODE_BUF) ^ NODE_BUF) |
                            ((bits == rem) ? NODE_TERMINAL : 0u);
-    u32 *st = vary ? vary + (size_t)i * NODE_STAT_WORDS : nullptr;
+    u32 *st = vary && nd.len >= stat_min_len ? vary + (size_t)i * NODE_STAT_WORDS : nullptr;   // (as level_hist)
     const u32 hv = st ? st[0] : 64u;
     u32 n_eq = st ? st[2] : 0u;
     u32 ridx = 0;                                 // the candidate with most copies (deep levels count three)
@@ -669,13 +676,14 @@ __global__ __launch_bounds__(256) void level_children_kernel(Node *nodes, u32 n_
 }
 
 hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *hist, Node *next, u32 *vary, const u64 *buf0,
-                                 const u64 *buf1, hipStream_t s)
+                                 const u64 *buf1, u32 stat_min_len, hipStream_t s)
 {
     // `hist` here is the tot table (same geometry as the hist table); the prefix kernel is launched
     // separately by the host through launch_level_prefix
     if (n_nodes == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(level_children_kernel, dim3(n_nodes), dim3(256), 0, s, nodes, n_nodes, hist, next, vary, buf0, buf1);
+    hipLaunchKernelGGL(level_children_kernel, dim3(n_nodes), dim3(256), 0, s, nodes, n_nodes, hist, next, vary, buf0, buf1,
+                       stat_min_len);
     return hipGetLastError();
 }
 

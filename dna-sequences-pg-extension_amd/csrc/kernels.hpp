@@ -97,7 +97,7 @@ hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, con
 hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunks, int src_dna,
                              const u64 *words, u64 n_words, u64 first, int k, const u64 *buf0,
                              const u64 *buf1, u32 *hist, u32 flt_lo, u32 flt_span, u32 flt_tb, u32 *vary, int multi_ref,
-                             hipStream_t s);
+                             u32 stat_min_len, hipStream_t s);
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
@@ -106,8 +106,9 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
 // in digit (= key) order, tot row overwritten with each digit's absolute base
 // vary (may be null): per node NODE_STAT_WORDS words -- the number of low key bits that vary inside it, keys below /
 // equal to its first key -- as level_hist found (key-source levels); a node whose keys all share this level's digit is flagged NODE_SKIP and stays where it is
+// (stat_min_len: the statistics exist for nodes of at least that many keys only)
 hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *tot, Node *next, u32 *vary, const u64 *buf0,
-                                 const u64 *buf1, hipStream_t s);
+                                 const u64 *buf1, u32 stat_min_len, hipStream_t s);
 // the chunks of nodes that level_children flagged NODE_PEEL (stat = the NODE_STAT_WORDS-per-node table)
 hipError_t launch_peel_scatter(const Node *nodes, u32 n_nodes, const Chunk *chunks, u32 n_chunks, Node *next, u64 *buf0,
                                u64 *buf1, u32 *stat, hipStream_t s);
