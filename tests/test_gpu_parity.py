@@ -515,6 +515,28 @@ def test_count_keys_device(ctx):
     d.free()
 
 
+@pytest.mark.parametrize("heavy,copies,light", [(1, 5000, 0), (1, 5000, 477), (1, 6144, 0), (5, 1000, 1100),
+                                                (40, 100, 1500), (1, 3000, 3000), (2, 2500, 1), (1, 900, 100)])
+def test_count_keys_crafted_leaves(ctx, heavy, copies, light):
+    """single leaves with long bins (count_kernels.hip leaves_kernel: pivots, padding slots, the three leaf
+    classes): `heavy` keys of `copies` copies + `light` random keys, 64 such leaves side by side"""
+    rng = np.random.default_rng(heavy * 7919 + copies + light)
+    L, per, k = 64, heavy * copies + light, 31
+    ids = np.repeat(np.arange(L, dtype=np.uint64), per) << np.uint64(56)
+    pay = rng.integers(0, 2**56, L * per, dtype=np.uint64)
+    hv = rng.integers(0, 2**56, heavy, dtype=np.uint64)
+    hv[0] |= np.uint64(0xFFF << 44)                  # (one heavy key in the leaf's last bins)
+    pay.reshape(L, per)[:, :heavy * copies] = np.repeat(hv, copies)
+    keys = ids | pay
+    rng.shuffle(keys)
+    ok, oc = np.unique(keys, return_counts=True)
+    d = ctx.upload(keys, 32 * len(keys))             # the key array as the words of a packed sequence: device memory
+    h = ctx.count_keys_device(d.device_words, len(keys), k)      # (used as scratch by the count)
+    check_hist(h, ok, oc.astype(np.uint64), f"crafted leaves heavy={heavy}x{copies} light={light}")
+    h.free()
+    d.free()
+
+
 # ------------------------------------------------------------------ batched operators
 
 def test_kmer_hash_batch(ctx, survey_vectors):
