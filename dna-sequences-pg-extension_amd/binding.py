@@ -107,6 +107,8 @@ def lib():
     L.dnagpu_buffer_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_buffer_free.argtypes = [vp, vp]
     L.dnagpu_buffer_free.restype = None
+    L.dnagpu_buffer_download.argtypes = [vp, vp, C.c_uint64, vp]
+    L.dnagpu_buffer_upload.argtypes = [vp, vp, vp, C.c_uint64]
     L.dnagpu_kmer_hash.argtypes = [vp, vp, C.c_uint64, vp, C.c_int]
     L.dnagpu_kmer_match.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(_FilterC), vp, C.c_int]
     L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
@@ -407,6 +409,15 @@ class Context:
 
     def buffer_free(self, ptr):
         lib().dnagpu_buffer_free(self.h, ptr)
+
+    def download_u64(self, ptr, n):
+        out = np.empty(max(n, 1), dtype=np.uint64)
+        _chk(lib().dnagpu_buffer_download(self.h, ptr, n * 8, out.ctypes.data))
+        return out[:n]
+
+    def upload_u64(self, ptr, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        _chk(lib().dnagpu_buffer_upload(self.h, ptr, a.ctypes.data, a.size * 8))
 
     # ---- batched operators
     def kmer_hash(self, keys):

@@ -86,27 +86,6 @@ __device__ __forceinline__ int ceil_log2_u32(u32 x)
     return x <= 1 ? 0 : 32 - __clz(x - 1);
 }
 
-// Inclusive scan over the 64 lanes of a wave with DPP adds (row shifts inside rows of 16, then two row
-// broadcasts): six VALU instructions.  The __shfl_up form is six ds_bpermute round trips through
-// the LDS crossbar -- measured with cycle stamps, the 1024-element scan of a scatter tile cost
-// 3.2 K of the tile's 33 K cycles that way.
-__device__ __forceinline__ u32 wave_incl_scan(u32 x)
-{
-    int v = (int)x;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    return (u32)v;
-}
-// Sum over the wave, returned in every lane.
-__device__ __forceinline__ u32 wave_sum(u32 x)
-{
-    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
-}
-
 // In-place exclusive scan of arr[0..n) in LDS by NT threads; returns the total.  The caller has
 // synchronised before the call; the function synchronises before returning.
 template <int NT>

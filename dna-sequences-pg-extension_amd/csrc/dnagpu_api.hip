@@ -86,7 +86,11 @@ struct dnagpu_ctx {
     // per-call event list (profiling)
     std::vector<hipEvent_t> ev;
     std::vector<const char *> ev_names;
+    // pinned, device-visible host words: small results (totals, per-group counts) land here without a
+    // staging copy; read after hipStreamSynchronize
+    u64 *mailbox;
 };
+constexpr size_t MAILBOX_BYTES = 65536;
 
 struct dnagpu_dna {
     u64 *words;
@@ -230,6 +234,14 @@ extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
         delete ctx;
         return DNAGPU_ERR_HIP;
     }
+    ctx->mailbox = nullptr;
+    e = hipHostMalloc(reinterpret_cast<void **>(&ctx->mailbox), MAILBOX_BYTES, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_err("hipHostMalloc: %s", hipGetErrorString(e));
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return DNAGPU_ERR_OOM;
+    }
     *out_ctx = ctx;
     return DNAGPU_OK;
 }
@@ -245,6 +257,8 @@ extern "C" void dnagpu_destroy(dnagpu_ctx *ctx)
     for (hipEvent_t e : ctx->ev)
         hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
+    if (ctx->mailbox)
+        hipHostFree(ctx->mailbox);
     delete ctx;
 }
 
@@ -295,6 +309,30 @@ extern "C" void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr)
 {
     if (ctx)
         pool_free(ctx, dev_ptr);
+}
+
+extern "C" int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint64_t bytes, void *host)
+{
+    if (!ctx || (bytes && (!dev_ptr || !host)))
+        return DNAGPU_ERR_BAD_ARG;
+    if (bytes == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(host, dev_ptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dev_ptr || !host)))
+        return DNAGPU_ERR_BAD_ARG;
+    if (bytes == 0)
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dev_ptr, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -772,6 +810,53 @@ static int build_filter(const dnagpu_filter *f, int k, bool has_rows, FilterDev 
     return DNAGPU_OK;
 }
 
+// The same operator as per-position sets for the bit-sliced stream kernels.  *none: no row can match
+// (an `=` of another length, stray bits behind the right-hand kmer's length, a 'U' in the pattern).
+static int build_filter_bits(const dnagpu_filter *f, int k, bool has_rows, FilterBits *out, bool *none)
+{
+    FilterDev fd;
+    RC_TRY(build_filter(f, k, has_rows, &fd));          // argument checks and the reference's ERRORs
+    FilterBits fb;
+    for (int q = 0; q < 4; q++)
+        fb.sets[q] = 0xFFFFFFFFu;                        // N everywhere
+    fb.k = k;
+    *none = false;
+    auto put = [&](int i, u32 set) { fb.sets[i >> 3] = (fb.sets[i >> 3] & ~(15u << ((i & 7) * 4))) | (set << ((i & 7) * 4)); };
+    switch (f->kind) {
+    case DNAGPU_FILTER_EQUALS:
+    case DNAGPU_FILTER_STARTS_WITH: {
+        const int len = f->length;
+        if (fd.and_mask == 0 && fd.eq_value != 0) {      // build_filter's "matches nothing", or an empty prefix with bits
+            *none = true;
+            break;
+        }
+        if (len < 32 && len >= 0 && (f->bits >> (2 * len)) != 0) {
+            *none = true;                                // bits behind the right-hand kmer's own length never compare equal
+            break;
+        }
+        for (int i = 0; i < len && i < k; i++)
+            put(i, 1u << ((f->bits >> (2 * i)) & 3));
+        break;
+    }
+    case DNAGPU_FILTER_CONTAINS: {
+        size_t len = strnlen(f->pattern, sizeof f->pattern);
+        if ((int)len != k) {                             // only reachable without rows
+            *none = true;
+            break;
+        }
+        for (int i = 0; i < k; i++) {
+            int set = iupac_set(f->pattern[i]);
+            if (set == 0)
+                *none = true;                            // 'U' matches no base (dna.c:1070)
+            put(i, (u32)set);
+        }
+        break;
+    }
+    }
+    *out = fb;
+    return DNAGPU_OK;
+}
+
 extern "C" int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                                               const dnagpu_filter *filter, uint64_t first, uint64_t count,
                                               uint64_t *out_keys, uint64_t *out_pos, uint64_t cap,
@@ -780,47 +865,57 @@ extern "C" int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna 
     if (!ctx || !dna || !n_out)
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
-    FilterDev fd;
-    RC_TRY(build_filter(filter, k, count > 0, &fd));
+    FilterBits fb;
+    bool none = false;
+    RC_TRY(build_filter_bits(filter, k, count > 0, &fb, &none));
     *n_out = 0;
-    if (count == 0)
+    if (count == 0 || none)
         return DNAGPU_OK;
     if (count > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
     HIP_TRY(hipSetDevice(ctx->device));
     PoolScope ps(ctx);
-    const u64 n_tiles = (count + FILTER_TILE - 1) / FILTER_TILE;
-    u32 *tile_counts = nullptr, *scan_tmp = nullptr, *total_d = nullptr;
-    RC_TRY(ps.alloc((size_t)n_tiles, &tile_counts));
-    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_tiles), &scan_tmp));
-    RC_TRY(ps.alloc(4, &total_d));
-    HIP_TRY(launch_filter_count(dna->words, dna->n_words, first, count, k, fd, tile_counts, ctx->stream));
-    HIP_TRY(launch_scan_u32(tile_counts, tile_counts, n_tiles, scan_tmp, total_d, ctx->stream));
-    u32 total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, total_d, 4, hipMemcpyDeviceToHost, ctx->stream));
+    u32 n_groups = 0, tpg = 0;
+    filter_bits_geometry(count, &n_groups, &tpg);
+    u32 *group_counts = nullptr;
+    RC_TRY(ps.alloc((size_t)n_groups, &group_counts));
+    prof_begin(ctx);
+    prof_mark(ctx, "filter_count");
+    HIP_TRY(launch_filter_bits_count(dna->words, dna->n_words, first, count, fb, group_counts, ctx->stream));
+    const bool want = cap > 0 && (out_keys || out_pos);
+    if (want && out_on_device) {
+        // both sweeps queued back to back; the total arrives in the pinned mailbox
+        prof_mark(ctx, "filter_write");
+        HIP_TRY(launch_filter_bits_write(dna->words, dna->n_words, first, count, k, fb, group_counts, out_keys,
+                                         out_pos, cap, ctx->mailbox, ctx->stream));
+        prof_mark(ctx, "end");
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        prof_end(ctx);
+        *n_out = ctx->mailbox[0];
+        return DNAGPU_OK;
+    }
+    static_assert(MAILBOX_BYTES >= FILTER_MAX_GROUPS * sizeof(u32), "mailbox holds one count per group");
+    u32 *hc = reinterpret_cast<u32 *>(ctx->mailbox);
+    HIP_TRY(hipMemcpyAsync(hc, group_counts, (size_t)n_groups * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    u64 total = 0;
+    for (u32 g = 0; g < n_groups; g++)
+        total += hc[g];
     *n_out = total;
     u64 nwrite = std::min<u64>(total, cap);
-    if (nwrite == 0 || (!out_keys && !out_pos))
+    if (nwrite == 0 || !want)
         return DNAGPU_OK;
     u64 *dk = nullptr, *dp = nullptr;
-    if (out_on_device) {
-        dk = out_keys;
-        dp = out_pos;
-    } else {
-        if (out_keys)
-            RC_TRY(ps.alloc((size_t)nwrite, &dk));
-        if (out_pos)
-            RC_TRY(ps.alloc((size_t)nwrite, &dp));
-    }
-    HIP_TRY(launch_filter_write(dna->words, dna->n_words, first, count, k, fd, tile_counts, dk, dp, nwrite,
-                                ctx->stream));
-    if (!out_on_device) {
-        if (out_keys)
-            HIP_TRY(hipMemcpyAsync(out_keys, dk, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (out_pos)
-            HIP_TRY(hipMemcpyAsync(out_pos, dp, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    if (out_keys)
+        RC_TRY(ps.alloc((size_t)nwrite, &dk));
+    if (out_pos)
+        RC_TRY(ps.alloc((size_t)nwrite, &dp));
+    HIP_TRY(launch_filter_bits_write(dna->words, dna->n_words, first, count, k, fb, group_counts, dk, dp, nwrite,
+                                     nullptr, ctx->stream));
+    if (out_keys)
+        HIP_TRY(hipMemcpyAsync(out_keys, dk, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_pos)
+        HIP_TRY(hipMemcpyAsync(out_pos, dp, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
 }

@@ -95,108 +95,6 @@ hipError_t launch_extract(const u64 *words, u64 n_words, u64 first, u64 count, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// generate_kmers + WHERE: tile t covers rows [t*4096, (t+1)*4096).  Inside a tile, row r is handled
-// by thread r % 256 in iteration r / 256, so a wave's ballot is in row order and a (iteration, wave)
-// table of popcounts gives every match its position-ordered slot without sorting.
-
-__global__ __launch_bounds__(256) void filter_count_kernel(const u64 *__restrict__ words, u64 n_words,
-                                                           u64 first, u64 count, u64 mask, FilterDev f,
-                                                           u32 *__restrict__ tile_counts)
-{
-    __shared__ u32 wsum[4];
-    const u64 base = (u64)blockIdx.x * FILTER_TILE;
-    u32 c = 0;
-#pragma unroll 4
-    for (int j = 0; j < FILTER_TILE / 256; j++) {
-        u64 i = base + (u64)j * 256 + threadIdx.x;
-        if (i < count)
-            c += filter_match(f, key_at(words, n_words, first + i, mask)) ? 1u : 0u;
-    }
-    for (int off = 32; off > 0; off >>= 1)
-        c += __shfl_down(c, off);
-    if ((threadIdx.x & 63) == 0)
-        wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        tile_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-hipError_t launch_filter_count(const u64 *words, u64 n_words, u64 first, u64 count, int k,
-                               const FilterDev &f, u32 *tile_counts, hipStream_t s)
-{
-    if (count == 0)
-        return hipSuccess;
-    unsigned grid = (unsigned)((count + FILTER_TILE - 1) / FILTER_TILE);
-    hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(256), 0, s, words, n_words, first, count,
-                       kmer_mask(k), f, tile_counts);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void filter_write_kernel(const u64 *__restrict__ words, u64 n_words,
-                                                           u64 first, u64 count, u64 mask, FilterDev f,
-                                                           const u32 *__restrict__ tile_offsets,
-                                                           u64 *__restrict__ out_keys,
-                                                           u64 *__restrict__ out_pos, u64 cap)
-{
-    constexpr int ITER = FILTER_TILE / 256;          // 16
-    __shared__ u32 cnt[ITER * 4];                    // [iteration][wave] popcounts -> exclusive offsets
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 base = (u64)blockIdx.x * FILTER_TILE;
-    u64 keys[ITER];
-    u64 ballots[ITER];
-#pragma unroll
-    for (int j = 0; j < ITER; j++) {
-        u64 i = base + (u64)j * 256 + threadIdx.x;
-        bool m = false;
-        keys[j] = 0;
-        if (i < count) {
-            keys[j] = key_at(words, n_words, first + i, mask);
-            m = filter_match(f, keys[j]);
-        }
-        ballots[j] = __ballot(m);
-        if (lane == 0)
-            cnt[j * 4 + wave] = (u32)__popcll(ballots[j]);
-    }
-    __syncthreads();
-    if (wave == 0) {                                 // 64 table entries: one wave scans them
-        u32 v = cnt[lane], inc = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            u32 t = __shfl_up(inc, off);
-            if (lane >= off)
-                inc += t;
-        }
-        cnt[lane] = inc - v;
-    }
-    __syncthreads();
-    const u64 tile_off = tile_offsets[blockIdx.x];
-    const u64 below = ((u64)1 << lane) - 1;
-#pragma unroll
-    for (int j = 0; j < ITER; j++) {
-        if ((ballots[j] >> lane) & 1) {
-            u64 idx = tile_off + cnt[j * 4 + wave] + (u64)__popcll(ballots[j] & below);
-            if (idx < cap) {
-                if (out_keys)
-                    __builtin_nontemporal_store(keys[j], &out_keys[idx]);
-                if (out_pos)
-                    __builtin_nontemporal_store((u64)(first + base + (u64)j * 256 + threadIdx.x), &out_pos[idx]);
-            }
-        }
-    }
-}
-
-hipError_t launch_filter_write(const u64 *words, u64 n_words, u64 first, u64 count, int k,
-                               const FilterDev &f, const u32 *tile_offsets, u64 *out_keys,
-                               u64 *out_pos, u64 cap, hipStream_t s)
-{
-    if (count == 0)
-        return hipSuccess;
-    unsigned grid = (unsigned)((count + FILTER_TILE - 1) / FILTER_TILE);
-    hipLaunchKernelGGL(filter_write_kernel, dim3(grid), dim3(256), 0, s, words, n_words, first, count,
-                       kmer_mask(k), f, tile_offsets, out_keys, out_pos, cap);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // batched operators over key arrays
 
 __global__ __launch_bounds__(256) void hash_batch_kernel(const u64 *__restrict__ keys, u64 n,

@@ -13,14 +13,18 @@ hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 moti
 hipError_t launch_extract(const u64 *words, u64 n_words, u64 first, u64 count, int k, u64 *out_keys,
                           hipStream_t s);
 
-// position-ordered filtered extraction, two sweeps over the (tiny) packed input:
-//   count sweep -> per-tile match counts; exclusive scan; write sweep -> compacted keys/positions
-constexpr int FILTER_TILE = 4096;
-hipError_t launch_filter_count(const u64 *words, u64 n_words, u64 first, u64 count, int k,
-                               const FilterDev &f, u32 *tile_counts, hipStream_t s);
-hipError_t launch_filter_write(const u64 *words, u64 n_words, u64 first, u64 count, int k,
-                               const FilterDev &f, const u32 *tile_offsets, u64 *out_keys,
-                               u64 *out_pos, u64 cap, hipStream_t s);
+// position-ordered filtered extraction (filter_kernels.hip), two sweeps over the (tiny) packed input:
+//   count sweep -> matches per workgroup range (filter_bits_geometry groups, group_counts[g]);
+//   write sweep -> every group sums the counts before it, then writes keys / positions (either may be
+//   null) of rows whose output index is < cap; *total_out (may be null, may be host-mapped memory) receives
+//   the number of matching rows
+constexpr int FILTER_MAX_GROUPS = 8192;
+void filter_bits_geometry(u64 count, u32 *n_groups, u32 *tiles_per_group);
+hipError_t launch_filter_bits_count(const u64 *words, u64 n_words, u64 first, u64 count, const FilterBits &fb,
+                                    u32 *group_counts, hipStream_t s);
+hipError_t launch_filter_bits_write(const u64 *words, u64 n_words, u64 first, u64 count, int k, const FilterBits &fb,
+                                    const u32 *group_counts, u64 *out_keys, u64 *out_pos, u64 cap, u64 *total_out,
+                                    hipStream_t s);
 
 hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s);
 hipError_t launch_match_batch(const u64 *keys, u64 n, const FilterDev &f, uint8_t *flags, hipStream_t s);

@@ -90,6 +90,14 @@ __device__ __forceinline__ bool filter_match(const FilterDev &f, u64 key)
     return bad == 0;
 }
 
+// The same three operators as per-position sets for the bit-sliced stream test of
+// filter_kernels.hip: position i of the k-mer must carry a code of sets[i] (4-bit mask, bit c = code c
+// allowed; 0xF = any).  `=` is k singletons, `^@` a prefix of singletons, `@>` the IUPAC text.
+struct FilterBits {
+    u32 sets[4];   // 32 positions x 4 bits, position i at bits 4*(i%8) of sets[i/8]
+    int k;
+};
+
 // relaxed, agent-scope 8-byte accesses for words shared between workgroups inside one launch
 // (self-validating {flag, value} granules: the only inter-workgroup hand-off used here)
 __device__ __forceinline__ u64 ld_agent(const u64 *p)
@@ -99,6 +107,27 @@ __device__ __forceinline__ u64 ld_agent(const u64 *p)
 __device__ __forceinline__ void st_agent(u64 *p, u64 v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Inclusive scan over the 64 lanes of a wave with DPP adds (row shifts inside rows of 16, then two row
+// broadcasts): six VALU instructions.  The __shfl_up form is six ds_bpermute round trips through
+// the LDS crossbar -- measured with cycle stamps, the 1024-element scan of a scatter tile cost
+// 3.2 K of the tile's 33 K cycles that way.
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (u32)v;
+}
+// Sum over the wave, returned in every lane.
+__device__ __forceinline__ u32 wave_sum(u32 x)
+{
+    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
 }
 
 }  // namespace dnagpu

@@ -214,6 +214,10 @@ int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                            uint64_t **dev_keys, uint64_t *owner_offsets);
 int dnagpu_buffer_alloc(dnagpu_ctx *ctx, uint64_t bytes, void **dev_ptr);
 void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr);
+/* Copies between host memory and a device buffer on the context's stream and waits for the copy
+ * (what the glue does with device-resident results before it builds Datums from them). */
+int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint64_t bytes, void *host);
+int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint64_t bytes);
 
 /* ---- batched operators over arrays of keys (bulk scans of stored kmer columns) -------------- */
 

@@ -256,6 +256,68 @@ def test_contains_random(ctx, pkg, n):
     d.free()
 
 
+def test_filters_random_patterns_windows_alignment(ctx, pkg):
+    """random IUPAC patterns (every letter, both halves of a 32-base pattern), random k, unaligned windows,
+    device outputs at either 16-byte parity, keys-only / positions-only"""
+    import ctypes as C
+    rng = np.random.default_rng(20261004)
+    n = 70_000
+    words = orc.synth_words(31337, n)
+    d = ctx.upload(words, n)
+    letters = "ATCGWSMKRYBDHVN"
+    for trial in range(60):
+        k = int(rng.integers(1, 33))
+        # mostly N with a few constrained positions, so that something matches
+        pat = ["N"] * k
+        for _ in range(int(rng.integers(1, 5))):
+            pat[int(rng.integers(0, k))] = letters[int(rng.integers(0, len(letters)))]
+        pat = "".join(pat)
+        total = n - k + 1
+        first = int(rng.integers(0, total // 2))
+        count = int(rng.integers(0, total - first + 1))
+        wk, wp = orc.generate_kmers_contains(words, n, k, pat)
+        sel = (wp >= first) & (wp < first + count)
+        gk, gp, tot = ctx.generate_kmers_filtered(d, k, pkg.Filter.contains(pat), first=first, count=count)
+        assert tot == int(sel.sum()), f"{pat} k={k} first={first} count={count}: {tot} vs {int(sel.sum())}"
+        assert_same(gk, wk[sel], f"{pat} k={k} window keys")
+        assert_same(gp, wp[sel], f"{pat} k={k} window positions")
+    # device outputs: both parities of the 16-byte alignment, keys only, positions only, small cap
+    k, pat = 21, "NNNNNNNNNNWSNNNNNNNNN"
+    wk, wp = orc.generate_kmers_contains(words, n, k, pat)
+    nk = n - k + 1
+    for koff, poff in ((0, 0), (8, 8), (8, 0), (0, 8)):
+        kb, pb = ctx.buffer_alloc(nk * 8 + 16), ctx.buffer_alloc(nk * 8 + 16)
+        for want_k, want_p, cap in ((True, True, nk), (True, False, nk), (False, True, nk), (True, True, 1001)):
+            m = ctx.count_matches_device(d, k, pkg.Filter.contains(pat), 0, nk,
+                                         C.c_void_p(kb + koff) if want_k else None,
+                                         C.c_void_p(pb + poff) if want_p else None, cap)
+            assert m == len(wk)
+            w = min(cap, m)
+            if want_k:
+                assert_same(ctx.download_u64(kb + koff, w), wk[:w], f"device keys off {koff}/{poff} cap {cap}")
+            if want_p:
+                assert_same(ctx.download_u64(pb + poff, w), wp[:w], f"device positions off {koff}/{poff} cap {cap}")
+        ctx.buffer_free(kb)
+        ctx.buffer_free(pb)
+    # cap = 0 / no outputs: the count alone
+    assert ctx.count_matches_device(d, k, pkg.Filter.contains(pat), 0, nk, None, None, 0) == len(wk)
+    d.free()
+
+
+@pytest.mark.parametrize("n", [8192 * 8192 + 77, 40_000_003])
+def test_contains_many_groups(ctx, pkg, n):
+    """more tiles than workgroups of one sweep: several tiles per group, running offsets across tiles"""
+    words = orc.synth_words(0xF00D, n)
+    d = ctx.upload(words, n)
+    for pat in ("NNNNNNNNNNWSNNNNNNNNN", "ACNNNNNNNNNNNNNNNNNNG"):
+        wk, wp = orc.generate_kmers_contains(words, n, 21, pat)
+        gk, gp, tot = ctx.generate_kmers_filtered(d, 21, pkg.Filter.contains(pat))
+        assert tot == len(wk)
+        assert_same(gk, wk, f"{pat} keys n={n}")
+        assert_same(gp, wp, f"{pat} positions n={n}")
+    d.free()
+
+
 def test_starts_with_and_equals_random(ctx, pkg):
     n = 300_001
     words = orc.synth_words(99, n)
@@ -565,6 +627,15 @@ def test_kmer_match_batch(ctx, pkg):
     want = np.zeros(len(keys), dtype=bool)
     want[wp.astype(np.int64)] = True
     assert np.array_equal(ctx.kmer_match(keys, k, pkg.Filter.starts_with(ln, bits)), want)
+    # kmer = q over the array (kmer_eq, dna.c:655-668): the rows that hold one given k-mer; a q of another length never equals
+    q = int(keys[777])
+    assert np.array_equal(ctx.kmer_match(keys, k, pkg.Filter.equals(k, q)), keys == np.uint64(q))
+    assert ctx.kmer_match(keys, k, pkg.Filter.equals(k, q)).sum() >= 1
+    assert not ctx.kmer_match(keys, k, pkg.Filter.equals(k - 1, q & ((1 << (2 * (k - 1))) - 1))).any()
+    keys8 = orc.generate_kmers(words, n, 8, faithful=False)
+    q8 = int(keys8[99])
+    got8 = ctx.kmer_match(keys8, 8, pkg.Filter.equals(8, q8))
+    assert np.array_equal(got8, keys8 == np.uint64(q8)) and got8.sum() >= 1
     with pytest.raises(pkg.DnaGpuError):
         ctx.kmer_match(keys, k, pkg.Filter.contains("ACG"))
 
@@ -646,6 +717,24 @@ def test_config2_k21_100M_against_oracle_summary(ctx):
     assert_same(gk, ok, "config 2 keys")
     assert_same(gc, oc, "config 2 counts")
     h.free()
+    d.free()
+
+
+def test_config5_k21_100M_contains(ctx, pkg):
+    """BASELINE config 5 at its stated size: qkmer @> fused into the k=21 extraction over the 100 Mbase
+    config-2 sequence (contains, dna.c:1091-1135; row order test.sql:86-92): keys, positions and the
+    total equal the oracle's, for a pattern of selectivity 1/4 in the middle of the k-mer, one at its
+    start, and a selective one (1/256)."""
+    n, k, seed = 100_000_000, 21, 0xD2A0001
+    words = orc.synth_words(seed, n)
+    d = ctx.synth(seed, n)
+    for pat in ("NNNNNNNNNNWSNNNNNNNNN", "RYNNNNNNNNNNNNNNNNNNN", "ACNNNNNNNNNNNNNNNNGTN"):
+        wk, wp = orc.generate_kmers_contains(words, n, k, pat)
+        gk, gp, tot = ctx.generate_kmers_filtered(d, k, pkg.Filter.contains(pat))
+        assert tot == len(wk), f"{pat}: {tot} matches, oracle {len(wk)}"
+        assert_same(gk, wk, f"config 5 {pat} keys")
+        assert_same(gp, wp, f"config 5 {pat} positions")
+        del wk, wp, gk, gp
     d.free()
 
 
