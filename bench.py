@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers/sec for the k=31 count over 3 Gbase synthetic (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (default: --config 4, the headline)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --config {2,3,4,5} [--motif M] [--pattern P]   the other BASELINE.json configs / repeat-rich variants
 
 A step = one full GROUP BY count over the whole synthetic sequence (extraction fused in), input
 already resident in HBM.  N=1: the single-GPU path (dnagpu_count_kmers) on all 3 Gbase.  N>1:
@@ -26,8 +27,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-SEED = 0xD2A0003
 CPU_SAMPLE_BASES = 24_000_000  # bounded sample for the CPU baseline (about 10-20 s on one core)
+
+# BASELINE.json configs: synthetic packed words, word w = splitmix64(seed + w)
+CONFIGS = {
+    2: {"n_bases": 100_000_000, "k": 21, "seed": 0xD2A0001, "kind": "count"},
+    3: {"n_bases": 248_956_422, "k": 31, "seed": 0xD2A0002, "kind": "count"},
+    4: {"n_bases": 3_000_000_000, "k": 31, "seed": 0xD2A0003, "kind": "count"},      # the headline (default)
+    5: {"n_bases": 100_000_000, "k": 21, "seed": 0xD2A0001, "kind": "filter", "pattern": "NNNNNNNNNNWSNNNNNNNNN"},
+}
+HEADLINE_METRIC = "k-mers/sec for k=31 count over 3 Gbase synthetic; % of HBM-read roofline"
 
 # algorithmic HBM bytes of each phase per k-mer (n) / per distinct k-mer (d); DESIGN.md "kernels"
 # (n = this rank's k-mers, d = its distinct k-mers, N = k-mers of the whole sequence: a sharded rank sweeps
@@ -38,6 +47,7 @@ PHASE_BYTES = {
     "hist": lambda n, d, N: 8.0 * n,                # keys in
     "scatter": lambda n, d, N: 16.0 * n,            # keys in, keys out
     "leaves": lambda n, d, N: 8.0 * n + 12.0 * d,   # keys in, (u64 key, u32 count) groups out
+    "dense": lambda n, d, N: 0.25 * N,              # short k-mers: the packed input per pass
 }
 
 
@@ -56,16 +66,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-bases", type=float, default=3e9)
-    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
+                    help="BASELINE.json config: 2 (k=21 count, 100 Mbase), 3 (k=31 count, chr1 scale), "
+                         "4 (k=31 count, 3 Gbase: the headline, default), 5 (qkmer @> fused into k=21 extraction)")
+    ap.add_argument("--n-bases", type=float, default=None, help="override the config's sequence length")
+    ap.add_argument("--k", type=int, default=None, help="override the config's k")
+    ap.add_argument("--motif", type=int, default=0,
+                    help="repeat-rich variant (SURVEY.md 8(d)): tile the first MOTIF bases over the second half")
+    ap.add_argument("--pattern", type=str, default=None, help="config 5: the qkmer pattern (length k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    cfg = dict(CONFIGS[args.config])
+    if args.n_bases is not None:
+        cfg["n_bases"] = int(args.n_bases)
+    if args.k is not None:
+        cfg["k"] = args.k
+    if args.pattern is not None:
+        cfg["pattern"] = args.pattern
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_bases, k = int(args.n_bases), args.k
+    n_bases, k, seed = cfg["n_bases"], cfg["k"], cfg["seed"]
     n_kmers = n_bases - k + 1
+    is_filter = cfg["kind"] == "filter"
+    if is_filter and world > 1:
+        raise SystemExit("config 5 is a single-GPU workload (BASELINE.json)")
 
     import torch
     from __graft_entry__ import load_package
@@ -97,9 +123,22 @@ def main():
 
     phases_acc = {}
     distinct = [0]
+    matches = [0]
+    extra = {}
 
-    if world == 1:
-        dna = ctx.synth(SEED, n_bases)
+    if is_filter:
+        import ctypes as C
+        dna = ctx.synth(seed, n_bases, motif_len=args.motif)
+        flt = pkg.Filter.contains(cfg["pattern"])
+        # outputs (keys and positions) stay in device memory, sized for every row
+        kb, pb = ctx.buffer_alloc(n_kmers * 8), ctx.buffer_alloc(n_kmers * 8)
+
+        def step():
+            matches[0] = ctx.count_matches_device(dna, k, flt, 0, n_kmers, C.c_void_p(kb), C.c_void_p(pb), n_kmers)
+            for name, ms in ctx.last_phase_times():
+                phases_acc.setdefault(name, []).append(ms)
+    elif world == 1:
+        dna = ctx.synth(seed, n_bases, motif_len=args.motif)
 
         def step():
             h = ctx.count_kmers(dna, k)
@@ -109,6 +148,8 @@ def main():
             h.free()
     else:
         import importlib
+        if args.motif:
+            raise SystemExit("--motif is a single-GPU option")
         sh = importlib.import_module(pkg.__name__ + ".sharded")
         engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", local_rank))
         state = {"chunk": None}
@@ -116,7 +157,7 @@ def main():
         def step():
             # resident input = this rank's word chunk of the packed sequence; the step all-gathers
             # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
-            h, state["chunk"] = sh.count_sharded(engine, SEED, n_bases, k, rank, world, state["chunk"])
+            h, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
             distinct[0] = h.distinct
             for name, ms in ctx.last_phase_times():
                 phases_acc.setdefault(name, []).append(ms)
@@ -140,43 +181,94 @@ def main():
         dist.all_reduce(dsum)
         distinct[0] = int(dsum.item())
 
+    if rank == 0 and world == 1 and not is_filter:
+        # outside the timed region: what the ascending-key view of the same histogram costs on the device
+        # (dnagpu_hist_sorted_view: segment directory -> two dense uint64 arrays); groups are stored in
+        # completion order, PostgreSQL's GROUP BY order is unspecified too (test.sql:95-104)
+        try:
+            import ctypes as C
+            h = ctx.count_kmers(dna, k)
+            d = h.distinct
+            vk, vc = ctx.buffer_alloc(max(d, 1) * 8), ctx.buffer_alloc(max(d, 1) * 8)
+            h.sorted_view_device(C.c_void_p(vk), C.c_void_p(vc))        # builds the directory prefix once
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            h.sorted_view_device(C.c_void_p(vk), C.c_void_p(vc))
+            extra["sorted_view_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+            ctx.buffer_free(vk)
+            ctx.buffer_free(vc)
+            h.free()
+        except Exception as e:                                          # never lose the line over the extra
+            extra["sorted_view_ms"] = None
+            extra["sorted_view_error"] = repr(e)[:200]
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_kmers * args.steps / elapsed
-        # dominant kernel of a step on this rank, by mean device time
         means = {name: sum(v) / len(v) for name, v in phases_acc.items()}
-        kern = {n_: m for n_, m in means.items() if phase_kind(n_)}
-        dom = max(kern, key=kern.get) if kern else None
-        roofline = None
-        if dom:
-            per_rank_n = n_kmers / world
-            per_rank_d = distinct[0] / world
-            alg_bytes = PHASE_BYTES[phase_kind(dom)](per_rank_n, per_rank_d, n_kmers)
-            achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 3),
-                        # PMC traffic was collected for the default single-GPU workload only
-                        "traffic": load_traffic(dom) if (world == 1 and n_bases == 3_000_000_000 and k == 31) else None}
         b_in = 8 * ((n_bases + 31) // 32)
         t_step = elapsed / args.steps
-        job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS / world, 5),
-               "alg_fraction": round((b_in + 16 * distinct[0]) / t_step / 1e9 / HBM_PEAK_GBS / world, 4),
-               "alg_bytes_per_kmer": round((b_in + 16 * distinct[0]) / n_kmers, 3)}
+        default_workload = (args.config == 4 and n_bases == CONFIGS[4]["n_bases"] and k == CONFIGS[4]["k"]
+                            and not args.motif)
+        roofline = None
+        if is_filter:
+            # dominant kernel: the write sweep (tests every row again, cuts and stores the matching keys + positions)
+            dom = "filter_write"
+            out_bytes = 16 * matches[0]
+            if dom in means and means[dom] > 0:
+                alg_bytes = b_in + out_bytes
+                achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 4),
+                            "traffic": load_traffic(f"config5:{dom}")}
+            job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS, 5),
+                   "alg_fraction": round((b_in + out_bytes) / t_step / 1e9 / HBM_PEAK_GBS, 4),
+                   "alg_bytes_per_row": round((b_in + out_bytes) / n_kmers, 3),
+                   "note": "compulsory output counted as 16 B per match (key + position, both written)"}
+            metric = (f"rows/sec scanned, qkmer @> fused into the k={k} extraction over {n_bases} synthetic bases; "
+                      "% of HBM-read roofline")
+            workload = (f"config 5: generate_kmers(dna,{k}) WHERE '{cfg['pattern']}' @> kmer over {n_bases} synthetic bases "
+                        f"(splitmix64 seed {seed:#x}{', motif ' + str(args.motif) if args.motif else ''}), keys + positions "
+                        "to device memory, single GPU")
+            unit = "rows/s"
+        else:
+            kern = {n_: m for n_, m in means.items() if phase_kind(n_)}
+            dom = max(kern, key=kern.get) if kern else None
+            if dom:
+                per_rank_n = n_kmers / world
+                per_rank_d = distinct[0] / world
+                alg_bytes = PHASE_BYTES[phase_kind(dom)](per_rank_n, per_rank_d, n_kmers)
+                achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 3),
+                            # PMC traffic is collected for the default single-GPU workload only
+                            "traffic": load_traffic(dom) if (world == 1 and default_workload) else None}
+            job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS / world, 5),
+                   "alg_fraction": round((b_in + 16 * distinct[0]) / t_step / 1e9 / HBM_PEAK_GBS / world, 4),
+                   "alg_bytes_per_kmer": round((b_in + 16 * distinct[0]) / n_kmers, 3)}
+            metric = HEADLINE_METRIC if args.config == 4 else \
+                f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline"
+            workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}"
+                        f"{', motif ' + str(args.motif) if args.motif else ''}), "
+                        f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-gather of the packed sequence + owner-filtered count'}")
+            unit = "k-mers/s"
         line = {
-            "metric": "k-mers/sec for k=31 count over 3 Gbase synthetic; % of HBM-read roofline",
-            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric,
+            "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"k={k} count over {n_bases} synthetic bases (splitmix64 seed {SEED:#x}), "
-                                   f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-gather of the packed sequence + owner-filtered count'}",
-                       "n_bases": n_bases, "k": k, "distinct": distinct[0]},
+            "config": {"workload": workload, "n_bases": n_bases, "k": k,
+                       **({"pattern": cfg["pattern"], "matches": matches[0]} if is_filter else {"distinct": distinct[0]}),
+                       **({"motif": args.motif} if args.motif else {})},
             "roofline": roofline,
             "job_roofline": job,
-            "phases_ms": {n_: round(m, 3) for n_, m in means.items()},
+            "phases_ms": {n_: round(m, 4) for n_, m in means.items()},
         }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(k)
+            line["cpu_baseline"] = cpu_baseline_filter(cfg, seed) if is_filter else cpu_baseline(k, seed)
         print(json.dumps(line), flush=True)
 
     if dist is not None:
@@ -196,6 +288,21 @@ def load_traffic(kernel):
         return None
 
 
+def cpu_baseline_filter(cfg, seed):
+    """Config 5's CPU leg: the oracle's per-row contains() loop (nucleotide_matches per base, dna.c:1064-1135)
+    fused with extraction, on one host core over a bounded sample of the same stream."""
+    import oracle as orc
+    n, k = CPU_SAMPLE_BASES, cfg["k"]
+    words = orc.synth_words(seed, n)
+    t0 = time.perf_counter()
+    wk, _ = orc.generate_kmers_contains(words, n, k, cfg["pattern"])
+    dt = time.perf_counter() - t0
+    return {"value": (n - k + 1) / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} bases of the same synthetic stream, k={k}, pattern {cfg['pattern']}: per-row "
+                      f"decode + contains() per base (dna.c:1091-1135), {len(wk)} matches, {dt:.1f} s",
+            "host_cores_available": os.cpu_count()}
+
+
 _CPU_PIECE = """
 import sys, time
 sys.path.insert(0, sys.argv[1])
@@ -208,7 +315,7 @@ print(time.perf_counter() - t0)
 """
 
 
-def cpu_baseline(k):
+def cpu_baseline(k, seed):
     """The oracle timed on this box's host: one core, like the reference's one PostgreSQL backend
     (generate_kmers is not PARALLEL SAFE, dna--1.0.sql:188-191), plus -- SURVEY.md 8(d) -- the same
     work on the box's CPU share with one independent piece per core (child processes with a hard
@@ -217,7 +324,7 @@ def cpu_baseline(k):
     import subprocess
     import oracle as orc
     n = CPU_SAMPLE_BASES
-    words = orc.synth_words(SEED, n)
+    words = orc.synth_words(seed, n)
     t0 = time.perf_counter()
     keys, counts = orc.count_kmers(words, n, k, faithful=True)
     dt = time.perf_counter() - t0
@@ -229,7 +336,7 @@ def cpu_baseline(k):
         cores = max(1, min(16, os.cpu_count() or 1))       # a one-GPU box's CPU share
         per = (n // cores) // 32 * 32
         t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, "-c", _CPU_PIECE, ROOT, str(SEED + c * (per // 32)), str(per), str(k)],
+        procs = [subprocess.Popen([sys.executable, "-c", _CPU_PIECE, ROOT, str(seed + c * (per // 32)), str(per), str(k)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in range(cores)]
         inner = []
         deadline = time.perf_counter() + 90.0               # for all the pieces together

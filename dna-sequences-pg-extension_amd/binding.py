@@ -20,6 +20,7 @@ ERR_OOM = 8
 ERR_HIP = 9
 ERR_DNA_EMPTY = 11
 ERR_DNA_INVALID_CHAR = 12
+DEBUG_POISON_POOL = 1
 
 FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2
@@ -101,6 +102,7 @@ def lib():
     L.dnagpu_hist_device_counts.restype = vp
     L.dnagpu_hist_download.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u64p, u64p]
     L.dnagpu_hist_summary.argtypes = [vp, vp, u64p, u64p, u64p]
+    L.dnagpu_hist_sorted_view.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp]
     L.dnagpu_hist_free.argtypes = [vp, vp]
     L.dnagpu_hist_free.restype = None
     L.dnagpu_partition_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp), u64p]
@@ -113,6 +115,7 @@ def lib():
     L.dnagpu_kmer_match.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(_FilterC), vp, C.c_int]
     L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
     L.dnagpu_set_profiling.argtypes = [vp, C.c_int]
+    L.dnagpu_set_debug.argtypes = [vp, C.c_uint]
     _LIB = L
     return L
 
@@ -220,6 +223,12 @@ class Hist:
                                         counts.ctypes.data_as(u64p)))
         return keys[:count], counts[:count]
 
+    def sorted_view_device(self, dev_keys, dev_counts, first=0, count=None):
+        """ascending-key groups [first, first+count) into caller-owned device arrays of uint64"""
+        if count is None:
+            count = self.distinct - first
+        _chk(lib().dnagpu_hist_sorted_view(self.ctx.h, self.h, first, count, dev_keys, dev_counts))
+
     def summary(self):
         """(total, distinct, unique, checksum) -- same tuple as the oracle's hist_summary"""
         t, u, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -236,6 +245,13 @@ class Context:
     def __init__(self, device=0):
         self.h = C.c_void_p()
         _chk(lib().dnagpu_init(device, C.byref(self.h)))
+        # test harness switch (this wrapper is test/bench tooling): DNAGPU_TEST_POISON=1 runs every context
+        # with DNAGPU_DEBUG_POISON_POOL, i.e. all work buffers pre-filled with 0xFF
+        if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0"):
+            self.set_debug(DEBUG_POISON_POOL)
+
+    def set_debug(self, flags):
+        _chk(lib().dnagpu_set_debug(self.h, int(flags)))
 
     def close(self):
         if self.h:

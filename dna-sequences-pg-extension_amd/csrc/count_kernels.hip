@@ -75,6 +75,24 @@ static void stamps_report(const char *what, int base, hipStream_t s)
 #define STAMP_FLUSH(base)
 #endif
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: remembered per HIP device, so a
+// process that opens contexts on several GPUs sets it on each
+enum { FA_SCATTER = 0, FA_LEAVES = 1, FA_DENSE = 2, FA_COUNT = 3 };
+static bool g_func_attrs[64][FA_COUNT];
+static inline bool func_attrs_ready(int what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return false;
+    return g_func_attrs[dev][what];
+}
+static inline void func_attrs_mark(int what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+        g_func_attrs[dev][what] = true;
+}
+
 constexpr int SC_THREADS = 1024;              // level_hist workgroup
 constexpr int SC_TILE = 8192;                 // keys staged in LDS per scatter tile
 
@@ -678,104 +696,6 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// level_scatter: one workgroup per chunk of a non-terminal split node.  Per tile of 8192 keys:
-//   rank   LDS atomic per key on its digit counter (order inside a digit is irrelevant: every
-//          later stage sorts)
-//   scan   exclusive scan of the counters
-//   stage  keys written digit-sorted into LDS
-//   write  thread i copies staged key i to out[base[d] + (i - excl[d])]: each digit's run is one
-//          contiguous, coalesced segment
-template <bool SRC_DNA, int NT, int ITEMS, int MINW>
-__global__ __launch_bounds__(NT, MINW) void level_scatter_kernel(const Node *__restrict__ nodes,
-                                                                   const Chunk *__restrict__ chunks, u32 n_chunks,
-                                                                   const u64 *__restrict__ words, u64 n_words,
-                                                                   u64 first, u64 mask, u64 *__restrict__ buf0,
-                                                                   u64 *__restrict__ buf1,
-                                                                   const u32 *__restrict__ hist,
-                                                                   const u32 *__restrict__ tot, int dbg)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *stage = reinterpret_cast<u64 *>(smem);                         // SC_TILE keys
-    u32 *excl = reinterpret_cast<u32 *>(smem + (size_t)(NT * ITEMS) * 8);    // ROW_STRIDE + 1
-    u32 *offs = excl + ROW_STRIDE + 4;                                  // ROW_STRIDE
-    u32 *wtmp = offs + ROW_STRIDE;                                      // NT / 64
-
-    if (blockIdx.x >= n_chunks)
-        return;
-    const Chunk ch = chunks[blockIdx.x];
-    const Node nd = nodes[ch.node];
-    const int bits = (int)nd.split;
-    const int rem = (int)(nd.meta & 0xff);
-    if (bits == rem || (nd.meta & (NODE_SKIP | NODE_PEEL)))
-        return;                                   // terminal split: children carry (key, count) already
-    const int shift = rem - bits;
-    const u32 R = 1u << bits, dmask = R - 1;
-    const u64 origin = (u64)nd.start + ch.off;
-    const u64 *__restrict__ src = SRC_DNA ? nullptr : (((nd.meta & NODE_BUF) ? buf1 : buf0) + origin);
-    // children of the dna root go to buffer 0; otherwise to the other buffer
-    u64 *__restrict__ dst = SRC_DNA ? buf0 : ((nd.meta & NODE_BUF) ? buf0 : buf1);
-
-    const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
-    const u32 *trow = tot + (u64)nd.chunk_base * ROW_STRIDE;
-#pragma unroll 1
-    for (u32 d = threadIdx.x; d < R; d += NT)
-        offs[d] = hrow[d] + trow[d];
-
-    for (u32 t0 = 0; t0 < ch.len; t0 += NT * ITEMS) {
-        const u32 tn = ch.len - t0 < (u32)(NT * ITEMS) ? ch.len - t0 : (u32)(NT * ITEMS);
-#pragma unroll 1
-        for (u32 d = threadIdx.x; d <= R; d += NT)
-            excl[d] = 0;
-        // Keys of this thread.  Slots past the end of the chunk are not branched around: they count
-        // in an extra digit R, which sorts them behind every real key (no exec-mask juggling).
-        u64 key[ITEMS];
-        if (SRC_DNA) {
-            Win16 w = win16_load(words, n_words, first + origin + t0 + threadIdx.x * ITEMS);
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++)
-                key[j] = win16_key(w, j, mask);
-        } else {
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                u32 i = threadIdx.x + j * NT;
-                key[j] = src[t0 + (i < tn ? i : tn - 1)];
-            }
-        }
-        __syncthreads();
-        u32 pos[ITEMS];        // rank inside the digit, then staged position
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
-            pos[j] = 0;
-            if (i < tn)
-                pos[j] = atomicAdd(&excl[(u32)(key[j] >> shift) & dmask], 1u);
-        }
-        __syncthreads();
-        block_scan_inplace<NT>(excl, (int)R + 1, wtmp);      // excl[R] = tn afterwards
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            u32 i = SRC_DNA ? threadIdx.x * ITEMS + j : threadIdx.x + j * NT;
-            if (i < tn)
-                stage[excl[(u32)(key[j] >> shift) & dmask] + pos[j]] = key[j];
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (u32 i = threadIdx.x; i < tn; i += NT) {
-            u64 kv = stage[i];
-            u32 d = (u32)(kv >> shift) & dmask;
-            if (dbg & 1)
-                dst[origin + t0 + i] = kv;      // timing ablation: same bytes, written linearly
-            else
-                dst[(u64)offs[d] + (i - excl[d])] = kv;
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (u32 d = threadIdx.x; d < R; d += NT)
-            offs[d] += excl[d + 1] - excl[d];
-        __syncthreads();
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // level_scatter with aligned write combining (the default).
@@ -1187,27 +1107,6 @@ __global__ __launch_bounds__(WC_THREADS, 4) void level_scatter_wc_dna_kernel(
     }
 }
 
-constexpr size_t SC_SMEM = (size_t)SC_TILE * 8 + (size_t)(ROW_STRIDE + 4) * 4 + (size_t)ROW_STRIDE * 4 + 16 * 4;
-
-template <int NT, int ITEMS, int MINW>
-static void launch_scatter_variant(int src_dna, u32 n_chunks, hipStream_t s, const Node *nodes, const Chunk *chunks,
-                                   const u64 *words, u64 n_words, u64 first, u64 mask, u64 *buf0, u64 *buf1,
-                                   const u32 *hist, const u32 *tot)
-{
-    static_assert(NT * ITEMS == SC_TILE, "tile size is fixed");
-    static int dbg = -1;
-    if (dbg < 0) {
-        const char *e = diag_env("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results are invalid when set
-        dbg = e ? atoi(e) : 0;
-    }
-    if (src_dna)
-        hipLaunchKernelGGL((level_scatter_kernel<true, NT, ITEMS, MINW>), dim3(n_chunks), dim3(NT), SC_SMEM, s,
-                           nodes, chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, dbg);
-    else
-        hipLaunchKernelGGL((level_scatter_kernel<false, NT, ITEMS, MINW>), dim3(n_chunks), dim3(NT), SC_SMEM, s,
-                           nodes, chunks, n_chunks, words, n_words, first, mask, buf0, buf1, hist, tot, dbg);
-}
-
 // ------------------------------------------------------------------------------------------------
 // peel_scatter: the chunks of NODE_PEEL nodes (dominated by their first key `ref`).  Keys below ref fill the
 // node's range from its start upwards, keys above it from its end downwards; copies of ref stay behind (their
@@ -1309,70 +1208,57 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
     if (n_chunks == 0)
         return hipSuccess;
     const DigitFilter flt{flt_lo, flt_span, flt_tb};
-    static int variant = -1;
-    if (variant < 0) {
-        const char *v = getenv("DNAGPU_SCATTER_VARIANT");
-        // 0 = 16384-key tile with aligned 64-byte write combining, next tile prefetched (every write
-        // request a full 64 B; one workgroup per CU); 1.. = 8192-key tile without combining (two
-        // workgroups per CU).  Both measure 16-18 ms per level at 3 Gbase; 0 is faster for R <= 512.
-        variant = v ? atoi(v) : 0;
-    }
     const u64 mask = kmer_mask(k);
-    if (variant == 0 || (src_dna && flt_span != ~0u)) {     // the owner filter lives in the dna root kernel
-        static bool attr_set = false;
-        static int nth_keys = 1024;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_dna_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(16));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS, 512));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wc_smem(WC_ITEMS_KEYS));
-            const char *e = diag_env("DNAGPU_WC_NTH");      // experiment: 512-thread workgroups (needs splits <= 9 bits)
-            nth_keys = e ? atoi(e) : 1024;
-            attr_set = true;
-        }
-        static int wdbg = -1;
-        if (wdbg < 0) {
-            const char *e = diag_env("DNAGPU_DEBUG_SCATTER");   // timing ablations only; results invalid when set
-            wdbg = e ? atoi(e) : 0;
-        }
-        if (src_dna && flt_span != ~0u)           // sharded count: sweep the whole sequence, keep this owner's keys
-            hipLaunchKernelGGL(level_scatter_wc_dna_kernel, dim3(n_chunks), dim3(WC_THREADS), wc_smem(16), s, nodes,
-                               chunks, n_chunks, words, n_words, first, mask, buf0, hist, tot, flt, wdbg);
-        else if (src_dna)                         // unfiltered root: one position per staged key, next tile
-            hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
-                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
-                               buf1, hist, tot, wdbg);
-        else if (nth_keys == 16 || (nth_keys == 1024 && max_bits <= 9))   // at most 512 digits: the carry of 128-byte flush units fits
-                                                  // (the dna root, write only, measured slower with them: 3.0 vs 2.65 ms at 1 Gbase)
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>), dim3(n_chunks), dim3(WC_THREADS),
-                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
-                               buf1, hist, tot, wdbg);
-        else if (nth_keys == 512)
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>), dim3(n_chunks), dim3(512),
-                               wc_smem(WC_ITEMS_KEYS, 512), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
-                               buf1, hist, tot, wdbg);
-        else
-            hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
-                               wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
-                               buf1, hist, tot, wdbg);
+    // 16384-key tiles with aligned 64-/128-byte write combining, next tile prefetched: every write request a
+    // full flush unit; one workgroup per CU.  (8192-key tiles without combining, two workgroups per CU, were
+    // the first version: 16-18 ms per level at 3 Gbase against 10.6-11.2 now.)
+    hipError_t ae = hipSuccess;
+    if (!func_attrs_ready(FA_SCATTER)) {
+        auto set = [&](const void *fn, size_t bytes) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess && ae == hipSuccess)
+                ae = e;
+        };
+        set(reinterpret_cast<const void *>(level_scatter_wc_dna_kernel), wc_smem(16));
+        set(reinterpret_cast<const void *>(level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>), wc_smem(WC_ITEMS_KEYS));
+        set(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>), wc_smem(WC_ITEMS_KEYS));
+        set(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>), wc_smem(WC_ITEMS_KEYS, 512));
+        set(reinterpret_cast<const void *>(level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>), wc_smem(WC_ITEMS_KEYS));
+        if (ae != hipSuccess)
+            return ae;
+        func_attrs_mark(FA_SCATTER);
+    }
+    static int nth_keys = -1, wdbg = -1;
+    if (nth_keys < 0) {
+        const char *e = diag_env("DNAGPU_WC_NTH");          // experiment: 512-thread workgroups (needs splits <= 9 bits)
+        nth_keys = e ? atoi(e) : 1024;
+        e = diag_env("DNAGPU_DEBUG_SCATTER");               // timing ablations only; results invalid when set
+        wdbg = e ? atoi(e) : 0;
+    }
+    if (src_dna && flt_span != ~0u)           // sharded count: sweep the whole sequence, keep this owner's keys
+        hipLaunchKernelGGL(level_scatter_wc_dna_kernel, dim3(n_chunks), dim3(WC_THREADS), wc_smem(16), s, nodes,
+                           chunks, n_chunks, words, n_words, first, mask, buf0, hist, tot, flt, wdbg);
+    else if (src_dna)                         // unfiltered root: one position per staged key, next tile
+        hipLaunchKernelGGL((level_scatter_wc_kernel<true, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
+                           wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                           buf1, hist, tot, wdbg);
+    else if (nth_keys == 16 || (nth_keys == 1024 && max_bits <= 9))   // at most 512 digits: the carry of 128-byte flush units fits
+                                              // (the dna root, write only, measured slower with them: 3.0 vs 2.65 ms at 1 Gbase)
+        hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 16>), dim3(n_chunks), dim3(WC_THREADS),
+                           wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                           buf1, hist, tot, wdbg);
+    else if (nth_keys == 512)
+        hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 512, 8>), dim3(n_chunks), dim3(512),
+                           wc_smem(WC_ITEMS_KEYS, 512), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                           buf1, hist, tot, wdbg);
+    else
+        hipLaunchKernelGGL((level_scatter_wc_kernel<false, WC_ITEMS_KEYS, 1024, 8>), dim3(n_chunks), dim3(WC_THREADS),
+                           wc_smem(WC_ITEMS_KEYS), s, nodes, chunks, n_chunks, words, n_words, first, mask, buf0,
+                           buf1, hist, tot, wdbg);
 #ifdef DNAGPU_STAMPS
-        if (!(src_dna && flt_span != ~0u))
-            stamps_report(src_dna ? "scatter_wc<dna>" : "scatter_wc<keys>", src_dna ? 0 : 12, s);
+    if (!(src_dna && flt_span != ~0u))
+        stamps_report(src_dna ? "scatter_wc<dna>" : "scatter_wc<keys>", src_dna ? 0 : 12, s);
 #endif
-        return hipGetLastError();
-    }
-    switch (variant) {
-    case 1: launch_scatter_variant<1024, 8, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
-    case 2: launch_scatter_variant<512, 16, 4>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
-    case 3: launch_scatter_variant<512, 16, 2>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
-    default: launch_scatter_variant<1024, 8, 8>(src_dna, n_chunks, s, nodes, chunks, words, n_words, first, mask, buf0, buf1, hist, tot); break;
-    }
     return hipGetLastError();
 }
 
@@ -1980,9 +1866,9 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_sma
     if (dbg < 0) {
         const char *e = diag_env("DNAGPU_DEBUG_LEAVES");   // timing ablations only; results are invalid when set
         dbg = e ? atoi(e) : 0;
-        const char *v = getenv("DNAGPU_LEAVES_VARIANT");
+        const char *v = diag_env("DNAGPU_LEAVES_VARIANT");  // experiment switches: diagnostic build only
         variant = v ? atoi(v) : 0;                       // 1024 threads x 4 keys, 64 VGPRs: 2 workgroups = 32 waves per CU
-        const char *m = getenv("DNAGPU_LEAVES_GRIDMULT");
+        const char *m = diag_env("DNAGPU_LEAVES_GRIDMULT");
         mult = m ? atoi(m) : 1;
         if (mult < 1)
             mult = 1;
@@ -2113,11 +1999,12 @@ int dense_max_bits() { return DENSE_MAX_BITS; }
 hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, u64 *out_keys,
                               u32 *out_counts, u64 *n_out, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_count_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BINS * 4);
-        attr_set = true;
+    if (!func_attrs_ready(FA_DENSE)) {
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_count_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BINS * 4);
+        if (ae != hipSuccess)
+            return ae;
+        func_attrs_mark(FA_DENSE);
     }
     hipError_t e = hipMemsetAsync(table, 0, ((size_t)1 << bits) * 4, s);
     if (e != hipSuccess)

@@ -53,6 +53,12 @@ extern "C" const char *dnagpu_strerror(int status)
 extern "C" const char *dnagpu_last_error(void) { return g_err; }
 extern "C" int dnagpu_abi_version(void) { return DNAGPU_ABI_VERSION; }
 
+#ifdef DNAGPU_STAMPS
+static inline const char *diag_env(const char *name) { return getenv(name); }
+#else
+static inline const char *diag_env(const char *) { return nullptr; }
+#endif
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -68,6 +74,23 @@ extern "C" int dnagpu_abi_version(void) { return DNAGPU_ABI_VERSION; }
         if (rc_ != DNAGPU_OK)  \
             return rc_;        \
     } while (0)
+
+// No C++ exception may cross the C-ABI (a PostgreSQL backend would die in std::terminate): every
+// extern "C" entry point that can allocate on the host (pool bookkeeping, event lists, node lists) runs its
+// body inside this guard.
+template <typename F>
+static int guarded(F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_err("host allocation failed");
+        return DNAGPU_ERR_OOM;
+    } catch (...) {
+        set_err("unexpected C++ exception");
+        return DNAGPU_ERR_INTERNAL;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // context + device buffer pool
@@ -89,6 +112,7 @@ struct dnagpu_ctx {
     // pinned, device-visible host words: small results (totals, per-group counts) land here without a
     // staging copy; read after hipStreamSynchronize
     u64 *mailbox;
+    unsigned debug_flags;     // DNAGPU_DEBUG_*
 };
 constexpr size_t MAILBOX_BYTES = 65536;
 
@@ -111,6 +135,15 @@ struct dnagpu_hist {
     u32 n_segs;
 };
 
+// DNAGPU_DEBUG_POISON_POOL: no work buffer starts out zeroed (fresh hipMalloc memory) or holding a
+// previous call's values (a recycled block); both hide reads of data the call never wrote
+static int pool_poison(dnagpu_ctx *ctx, void *p, size_t bytes)
+{
+    if (ctx->debug_flags & DNAGPU_DEBUG_POISON_POOL)
+        HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, ctx->stream));
+    return DNAGPU_OK;
+}
+
 static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
 {
     if (bytes == 0)
@@ -126,7 +159,7 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
     if (best >= 0) {
         ctx->pool[best].in_use = true;
         *out = ctx->pool[best].ptr;
-        return DNAGPU_OK;
+        return pool_poison(ctx, ctx->pool[best].ptr, ctx->pool[best].size);
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -151,7 +184,7 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
     }
     ctx->pool.push_back(PoolBlock{p, bytes, true});
     *out = p;
-    return DNAGPU_OK;
+    return pool_poison(ctx, p, bytes);
 }
 
 // Buffers go back to the pool while kernels that use them may still be queued: every later user is
@@ -207,6 +240,7 @@ struct PoolScope {
 
 extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
 {
+    return guarded([&]() -> int {
     if (!out_ctx)
         return DNAGPU_ERR_BAD_ARG;
     *out_ctx = nullptr;
@@ -235,6 +269,7 @@ extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
         return DNAGPU_ERR_HIP;
     }
     ctx->mailbox = nullptr;
+    ctx->debug_flags = 0;
     e = hipHostMalloc(reinterpret_cast<void **>(&ctx->mailbox), MAILBOX_BYTES, hipHostMallocDefault);
     if (e != hipSuccess) {
         set_err("hipHostMalloc: %s", hipGetErrorString(e));
@@ -244,6 +279,7 @@ extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
     }
     *out_ctx = ctx;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" void dnagpu_destroy(dnagpu_ctx *ctx)
@@ -264,16 +300,19 @@ extern "C" void dnagpu_destroy(dnagpu_ctx *ctx)
 
 extern "C" int dnagpu_synchronize(dnagpu_ctx *ctx)
 {
+    return guarded([&]() -> int {
     if (!ctx)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" void *dnagpu_stream(dnagpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" int dnagpu_trim(dnagpu_ctx *ctx)
 {
+    return guarded([&]() -> int {
     if (!ctx)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -286,6 +325,7 @@ extern "C" int dnagpu_trim(dnagpu_ctx *ctx)
         }
     }
     return DNAGPU_OK;
+    });
 }
 
 extern "C" uint64_t dnagpu_device_bytes(dnagpu_ctx *ctx)
@@ -299,10 +339,12 @@ extern "C" uint64_t dnagpu_device_bytes(dnagpu_ctx *ctx)
 
 extern "C" int dnagpu_buffer_alloc(dnagpu_ctx *ctx, uint64_t bytes, void **dev_ptr)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dev_ptr)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     return pool_alloc(ctx, (size_t)bytes, dev_ptr);
+    });
 }
 
 extern "C" void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr)
@@ -313,6 +355,7 @@ extern "C" void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr)
 
 extern "C" int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint64_t bytes, void *host)
 {
+    return guarded([&]() -> int {
     if (!ctx || (bytes && (!dev_ptr || !host)))
         return DNAGPU_ERR_BAD_ARG;
     if (bytes == 0)
@@ -321,10 +364,12 @@ extern "C" int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint
     HIP_TRY(hipMemcpyAsync(host, dev_ptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint64_t bytes)
 {
+    return guarded([&]() -> int {
     if (!ctx || (bytes && (!dev_ptr || !host)))
         return DNAGPU_ERR_BAD_ARG;
     if (bytes == 0)
@@ -333,6 +378,7 @@ extern "C" int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *
     HIP_TRY(hipMemcpyAsync(dev_ptr, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,20 +426,32 @@ static void prof_end(dnagpu_ctx *ctx)
     ctx->last_times.n = n;
 }
 
+extern "C" int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags)
+{
+    if (!ctx)
+        return DNAGPU_ERR_BAD_ARG;
+    ctx->debug_flags = flags;
+    return DNAGPU_OK;
+}
+
 extern "C" int dnagpu_last_phase_times(dnagpu_ctx *ctx, dnagpu_phase_times *out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out)
         return DNAGPU_ERR_BAD_ARG;
     *out = ctx->last_times;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_set_profiling(dnagpu_ctx *ctx, int enabled)
 {
+    return guarded([&]() -> int {
     if (!ctx)
         return DNAGPU_ERR_BAD_ARG;
     ctx->profiling = enabled != 0;
     return DNAGPU_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,6 +460,7 @@ static u64 words_for(u64 n_bases) { return (n_bases + 31) / 32; }
 
 extern "C" int dnagpu_dna_upload(dnagpu_ctx *ctx, const uint64_t *words, uint64_t n_bases, dnagpu_dna **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || (!words && n_bases))
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -425,11 +484,13 @@ extern "C" int dnagpu_dna_upload(dnagpu_ctx *ctx, const uint64_t *words, uint64_
     }
     *out = h;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_wrap(dnagpu_ctx *ctx, const uint64_t *dev_words, uint64_t n_words,
                                uint64_t n_bases, dnagpu_dna **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || (!dev_words && n_bases) || n_words < words_for(n_bases))
         return DNAGPU_ERR_BAD_ARG;
     dnagpu_dna *h = new (std::nothrow) dnagpu_dna{const_cast<u64 *>(dev_words), n_words, n_bases, false};
@@ -437,11 +498,13 @@ extern "C" int dnagpu_dna_wrap(dnagpu_ctx *ctx, const uint64_t *dev_words, uint6
         return DNAGPU_ERR_OOM;
     *out = h;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_synth(dnagpu_ctx *ctx, uint64_t seed, uint64_t n_bases, uint64_t motif_len,
                                 dnagpu_dna **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -461,10 +524,12 @@ extern "C" int dnagpu_dna_synth(dnagpu_ctx *ctx, uint64_t seed, uint64_t n_bases
     }
     *out = h;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t *words)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !words)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -474,11 +539,13 @@ extern "C" int dnagpu_dna_download(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint6
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_pack(dnagpu_ctx *ctx, const char *text, uint64_t n_bases, int text_on_device,
                                dnagpu_dna **out, uint64_t *bad_pos, char *bad_char)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out)
         return DNAGPU_ERR_BAD_ARG;
     if (n_bases == 0)
@@ -517,11 +584,13 @@ extern "C" int dnagpu_dna_pack(dnagpu_ctx *ctx, const char *text, uint64_t n_bas
     ps.release(words);
     *out = h;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_t first, uint64_t count,
                                  char *out_text, int out_on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || (count && !out_text))
         return DNAGPU_ERR_BAD_ARG;
     if (first > dna->n_bases || count > dna->n_bases - first)
@@ -538,6 +607,7 @@ extern "C" int dnagpu_dna_unpack(dnagpu_ctx *ctx, const dnagpu_dna *dna, uint64_
         HIP_TRY(hipMemcpyAsync(out_text, dt, count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" uint64_t dnagpu_dna_wire_size(uint64_t n_bases) { return 8 + 8 * words_for(n_bases); }
@@ -545,6 +615,7 @@ extern "C" uint64_t dnagpu_dna_wire_size(uint64_t n_bases) { return 8 + 8 * word
 extern "C" int dnagpu_dna_from_wire(dnagpu_ctx *ctx, const void *wire, uint64_t wire_bytes, int wire_on_device,
                                     dnagpu_dna **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !wire || !out || wire_bytes < 8)
         return DNAGPU_ERR_BAD_ARG;
     if (wire_on_device && (reinterpret_cast<uintptr_t>(wire) & 7))
@@ -596,11 +667,13 @@ extern "C" int dnagpu_dna_from_wire(dnagpu_ctx *ctx, const void *wire, uint64_t 
     }
     *out = h;
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_dna_to_wire(dnagpu_ctx *ctx, const dnagpu_dna *dna, void *wire, uint64_t wire_cap,
                                   int wire_on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !wire || wire_cap < dnagpu_dna_wire_size(dna->n_bases))
         return DNAGPU_ERR_BAD_ARG;
     if (wire_on_device && (reinterpret_cast<uintptr_t>(wire) & 7))
@@ -624,11 +697,13 @@ extern "C" int dnagpu_dna_to_wire(dnagpu_ctx *ctx, const dnagpu_dna *dna, void *
         HIP_TRY(hipMemcpyAsync(dst, stage, nw * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k, char *out_text,
                                     int on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || (n && (!keys || !out_text)))
         return DNAGPU_ERR_BAD_ARG;
     if (k <= 0 || k > 32)
@@ -651,6 +726,7 @@ extern "C" int dnagpu_kmers_to_text(dnagpu_ctx *ctx, const uint64_t *keys, uint6
         HIP_TRY(hipMemcpyAsync(out_text, dt, n * (u64)(k + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" uint64_t dnagpu_dna_length(const dnagpu_dna *dna) { return dna ? dna->n_bases : 0; }
@@ -669,12 +745,14 @@ extern "C" void dnagpu_dna_free(dnagpu_ctx *ctx, dnagpu_dna *dna)
 // generate_kmers
 extern "C" int dnagpu_kmer_count(uint64_t n_bases, int k, uint64_t *n_kmers)
 {
+    return guarded([&]() -> int {
     if (k <= 0 || k > 32)                      // dna.c:772
         return DNAGPU_ERR_INVALID_K;
     if (!n_kmers)
         return DNAGPU_ERR_BAD_ARG;
     *n_kmers = n_bases >= (u64)k ? n_bases - (u64)k + 1 : 0;   // dna.c:781 without the underflow
     return DNAGPU_OK;
+    });
 }
 
 // validates [first, first+count) against the row count of generate_kmers(dna, k)
@@ -693,6 +771,7 @@ static int check_range(const dnagpu_dna *dna, int k, u64 first, u64 count)
 extern "C" int dnagpu_generate_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
                                      uint64_t count, uint64_t *out_keys, int out_on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna)
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
@@ -719,6 +798,7 @@ extern "C" int dnagpu_generate_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return DNAGPU_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,6 +942,7 @@ extern "C" int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna 
                                               uint64_t *out_keys, uint64_t *out_pos, uint64_t cap,
                                               uint64_t *n_out, int out_on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !n_out)
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
@@ -918,12 +999,14 @@ extern "C" int dnagpu_generate_kmers_filtered(dnagpu_ctx *ctx, const dnagpu_dna 
         HIP_TRY(hipMemcpyAsync(out_pos, dp, nwrite * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
 // batched operators
 extern "C" int dnagpu_kmer_hash(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, uint32_t *out, int on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || (n && (!keys || !out)))
         return DNAGPU_ERR_BAD_ARG;
     if (n == 0)
@@ -944,11 +1027,13 @@ extern "C" int dnagpu_kmer_hash(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t 
     HIP_TRY(hipMemcpyAsync(out, dh, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
                                  const dnagpu_filter *filter, uint8_t *flags, int on_device)
 {
+    return guarded([&]() -> int {
     if (!ctx || (n && (!keys || !flags)))
         return DNAGPU_ERR_BAD_ARG;
     if (k <= 0 || k > 32)
@@ -973,6 +1058,7 @@ extern "C" int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t
     HIP_TRY(hipMemcpyAsync(flags, df, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1028,7 +1114,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 
     static u64 chunk_target = 0;                 // chunks per level (work units of the hist/scatter kernels)
     if (chunk_target == 0) {
-        const char *e = getenv("DNAGPU_CHUNKS");
+        const char *e = diag_env("DNAGPU_CHUNKS");       // experiment switch: diagnostic build (make STAMPS=1) only
         chunk_target = e ? (u64)atoll(e) : 4096;
         if (chunk_target < 256)
             chunk_target = 256;
@@ -1292,36 +1378,43 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
 extern "C" int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
                                   uint64_t count, dnagpu_hist **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !out)
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, dna, first, count, k, nullptr, out);
+    });
 }
 
 extern "C" int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
                                         uint64_t count, int owner, int n_owners, dnagpu_hist **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !out || n_owners < 1 || owner < 0 || owner >= n_owners)
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, owner, n_owners);
+    });
 }
 
 extern "C" int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || (n && !dev_keys))
         return DNAGPU_ERR_BAD_ARG;
     if (k <= 0 || k > 32)
         return DNAGPU_ERR_INVALID_K;
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, nullptr, 0, n, k, dev_keys, out);
+    });
 }
 
 extern "C" int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k,
                                           uint64_t key_min, uint64_t key_max, dnagpu_hist **out)
 {
+    return guarded([&]() -> int {
     if (!ctx || !out || (n && !dev_keys) || key_min > key_max)
         return DNAGPU_ERR_BAD_ARG;
     if (k <= 0 || k > 32)
@@ -1337,6 +1430,7 @@ extern "C" int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, u
     const u64 prefix = free_bits >= 64 ? 0 : (key_min >> free_bits) << free_bits;
     // a single possible key (fixed == 2k) still runs through the generic path: rem = 0 leaf
     return count_core(ctx, nullptr, 0, n, k, dev_keys, out, fixed, prefix);
+    });
 }
 
 extern "C" uint64_t dnagpu_hist_distinct(const dnagpu_hist *h) { return h ? h->n_distinct : 0; }
@@ -1346,9 +1440,53 @@ extern "C" const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { ret
 
 // Ascending-key order through the segment directory: groups are gathered on the device into a
 // staging window, then copied to the host.
+// exclusive scan of the segment sizes, built on the first ordered read of a histogram
+static int ensure_seg_pre(dnagpu_ctx *ctx, dnagpu_hist *h)
+{
+    if (h->seg_pre)
+        return DNAGPU_OK;
+    PoolScope ps(ctx);
+    u32 *pre = nullptr, *tmp = nullptr;
+    RC_TRY(pool_alloc_t(ctx, (size_t)h->n_segs + 1, &pre));
+    int rc = ps.alloc((size_t)scan_tmp_words(h->n_segs), &tmp);
+    hipError_t e = rc == DNAGPU_OK ? launch_scan_u32(h->seg_cnt, pre, h->n_segs, tmp, pre + h->n_segs, ctx->stream)
+                                   : hipSuccess;
+    if (rc != DNAGPU_OK || e != hipSuccess) {
+        pool_free(ctx, pre);
+        if (rc == DNAGPU_OK) {
+            set_err("segment scan: %s", hipGetErrorString(e));
+            rc = DNAGPU_ERR_HIP;
+        }
+        return rc;
+    }
+    h->seg_pre = pre;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_hist_sorted_view(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uint64_t first, uint64_t count,
+                                       uint64_t *dev_keys, uint64_t *dev_counts)
+{
+    return guarded([&]() -> int {
+    dnagpu_hist *h = const_cast<dnagpu_hist *>(h_c);
+    if (!ctx || !h)
+        return DNAGPU_ERR_BAD_ARG;
+    if (first > h->n_distinct || count > h->n_distinct - first)
+        return DNAGPU_ERR_BAD_ARG;
+    if (count == 0 || (!dev_keys && !dev_counts))
+        return DNAGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    RC_TRY(ensure_seg_pre(ctx, h));
+    HIP_TRY(launch_gather_sorted(h->seg_off, h->seg_cnt, h->seg_pre, h->n_segs, first, count, h->keys, h->counts,
+                                 dev_keys, dev_counts, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DNAGPU_OK;
+    });
+}
+
 extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uint64_t first, uint64_t count,
                                     uint64_t *keys, uint64_t *counts)
 {
+    return guarded([&]() -> int {
     dnagpu_hist *h = const_cast<dnagpu_hist *>(h_c);
     if (!ctx || !h)
         return DNAGPU_ERR_BAD_ARG;
@@ -1357,23 +1495,8 @@ extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uin
     if (count == 0 || (!keys && !counts))
         return DNAGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    RC_TRY(ensure_seg_pre(ctx, h));
     PoolScope ps(ctx);
-    if (!h->seg_pre) {
-        u32 *pre = nullptr, *tmp = nullptr;
-        RC_TRY(pool_alloc_t(ctx, (size_t)h->n_segs + 1, &pre));
-        int rc = ps.alloc((size_t)scan_tmp_words(h->n_segs), &tmp);
-        hipError_t e = rc == DNAGPU_OK ? launch_scan_u32(h->seg_cnt, pre, h->n_segs, tmp, pre + h->n_segs, ctx->stream)
-                                       : hipSuccess;
-        if (rc != DNAGPU_OK || e != hipSuccess) {
-            pool_free(ctx, pre);
-            if (rc == DNAGPU_OK) {
-                set_err("segment scan: %s", hipGetErrorString(e));
-                rc = DNAGPU_ERR_HIP;
-            }
-            return rc;
-        }
-        h->seg_pre = pre;
-    }
     const u64 BATCH = (u64)1 << 25;            // 32 Mi groups = 2 x 256 MiB staging
     u64 *sk = nullptr, *sc = nullptr;
     if (keys)
@@ -1391,11 +1514,13 @@ extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uin
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return DNAGPU_OK;
+    });
 }
 
 extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t *total, uint64_t *unique,
                                    uint64_t *checksum)
 {
+    return guarded([&]() -> int {
     if (!ctx || !h)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1411,6 +1536,7 @@ extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64
     if (unique) *unique = r[1];
     if (checksum) *checksum = r[2];
     return DNAGPU_OK;
+    });
 }
 
 extern "C" void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h)
@@ -1433,6 +1559,7 @@ extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, in
                                       uint64_t count, int n_owners, uint64_t **dev_keys,
                                       uint64_t *owner_offsets)
 {
+    return guarded([&]() -> int {
     if (!ctx || !dna || !dev_keys || !owner_offsets || n_owners < 1 || n_owners > (1 << MAX_SPLIT_BITS))
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
@@ -1472,4 +1599,5 @@ extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, in
     *dev_keys = tr.buf0;
     prof_end(ctx);
     return DNAGPU_OK;
+    });
 }

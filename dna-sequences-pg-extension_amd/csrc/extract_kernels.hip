@@ -413,8 +413,10 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(u32 *__restrict__ sums,
         *total = carry_sh;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const u32 *__restrict__ in, u32 *__restrict__ out,
-                                                                u64 n, const u32 *__restrict__ sums)
+// (in == out is allowed by launch_scan_u32's contract, so neither pointer is __restrict__: every value of a
+// thread's eight is loaded before its first store)
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const u32 *in, u32 *out, u64 n,
+                                                                const u32 *__restrict__ sums)
 {
     __shared__ u32 wtot[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -189,6 +189,10 @@ const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
  * NULL). */
 int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
                          uint64_t *keys, uint64_t *counts);
+/* Same view into device memory: groups [first, first+count) of the ascending-key order as two dense
+ * arrays of `count` uint64 each (either may be NULL), e.g. for a caller that post-processes on the GPU. */
+int dnagpu_hist_sorted_view(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
+                            uint64_t *dev_keys, uint64_t *dev_counts);
 /* total = sum(count), unique = count(*) FILTER (WHERE count = 1) (test.sql:112-114), checksum =
  * wrapping sum over groups of an order-independent digest of (key, count), computed on device. */
 int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t *total, uint64_t *unique,
@@ -212,6 +216,11 @@ int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint
 int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                            uint64_t first, uint64_t count, int n_owners,
                            uint64_t **dev_keys, uint64_t *owner_offsets);
+/* Device buffers from the context's pool.  Stream rule for every pooled buffer a caller touches with its
+ * own HIP work (these, *dev_keys of dnagpu_partition_kmers, the arrays of a dnagpu_hist): the pool recycles a
+ * block as soon as it is freed and orders reuse only on dnagpu_stream().  So (1) work a caller queues on
+ * another stream must be ordered behind dnagpu_stream() before it first touches a buffer, and (2) must have
+ * finished (or dnagpu_stream() must wait for it) before dnagpu_buffer_free / dnagpu_hist_free. */
 int dnagpu_buffer_alloc(dnagpu_ctx *ctx, uint64_t bytes, void **dev_ptr);
 void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr);
 /* Copies between host memory and a device buffer on the context's stream and waits for the copy
@@ -228,6 +237,13 @@ int dnagpu_kmer_hash(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, uint32_t
  * dnagpu_generate_kmers_filtered. */
 int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
                       const dnagpu_filter *filter, uint8_t *flags, int on_device);
+
+/* ---- debug aids (off by default) ---------------------------------------------------------------
+ * DNAGPU_DEBUG_POISON_POOL: every work buffer the pool hands out -- fresh or recycled, internal or through
+ * dnagpu_buffer_alloc -- is first filled with 0xFF bytes on the context's stream, so a kernel that reads a
+ * work buffer before writing it sees garbage in every run, not only in a warm context. */
+#define DNAGPU_DEBUG_POISON_POOL 1u
+int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------
  * Device time in milliseconds (HIP events on the context's stream) of the phases of the most

@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, "g*", "**", "*counter_collection.csv"), re
             short = name.split("(")[0].replace("void ", "").replace("dnagpu::", "")
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern in sorted(acc):
-    if any(x in kern for x in ("leaves", "scatter", "level_hist")):
+    if any(x in kern for x in ("leaves", "scatter", "level_hist", "fb_", "sk_", "mini")):
         print(kern)
         for c in sorted(acc[kern]):
             v = acc[kern][c]
