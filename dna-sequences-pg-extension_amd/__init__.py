@@ -16,6 +16,10 @@ from .binding import (  # noqa: F401
     DnaGpuError,
     Filter,
     Hist,
+    MULTI_AUTO,
+    MULTI_COPY,
+    MULTI_RCCL,
+    Multi,
     abi_version,
     kmer_count,
     lib,

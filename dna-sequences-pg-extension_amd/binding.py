@@ -113,6 +113,21 @@ def lib():
     L.dnagpu_buffer_upload.argtypes = [vp, vp, vp, C.c_uint64]
     L.dnagpu_kmer_hash.argtypes = [vp, vp, C.c_uint64, vp, C.c_int]
     L.dnagpu_kmer_match.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(_FilterC), vp, C.c_int]
+    L.dnagpu_multi_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+    L.dnagpu_multi_destroy.argtypes = [vp]
+    L.dnagpu_multi_destroy.restype = None
+    L.dnagpu_multi_size.argtypes = [vp]
+    L.dnagpu_multi_ctx.argtypes = [vp, C.c_int]
+    L.dnagpu_multi_ctx.restype = vp
+    L.dnagpu_multi_transport.argtypes = [vp]
+    L.dnagpu_multi_transport.restype = C.c_char_p
+    L.dnagpu_multi_dna_upload.argtypes = [vp, u64p, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_multi_dna_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_multi_dna_length.argtypes = [vp]
+    L.dnagpu_multi_dna_length.restype = C.c_uint64
+    L.dnagpu_multi_dna_free.argtypes = [vp, vp]
+    L.dnagpu_multi_dna_free.restype = None
+    L.dnagpu_count_multi.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
     L.dnagpu_set_profiling.argtypes = [vp, C.c_int]
     L.dnagpu_set_debug.argtypes = [vp, C.c_uint]
@@ -447,3 +462,67 @@ class Context:
         out = np.empty(max(a.size, 1), dtype=np.uint8)
         _chk(lib().dnagpu_kmer_match(self.h, a.ctypes.data, a.size, k, C.byref(flt.c), out.ctypes.data, 0))
         return out[:a.size].astype(bool)
+
+
+MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
+
+
+class _BorrowedContext(Context):
+    """a rank's context owned by a Multi: same methods, never destroyed from here"""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    def close(self):
+        self.h = None
+
+
+class Multi:
+    """dnagpu_multi: N ranks driven from this one process (dnagpu_count_multi)."""
+
+    def __init__(self, devices, transport=MULTI_AUTO):
+        n = len(devices)
+        arr = (C.c_int * n)(*devices)
+        self.h = C.c_void_p()
+        _chk(lib().dnagpu_multi_init(arr, n, transport, C.byref(self.h)))
+        self.n = n
+        self.ranks = [_BorrowedContext(lib().dnagpu_multi_ctx(self.h, r)) for r in range(n)]
+
+    @property
+    def transport(self):
+        return lib().dnagpu_multi_transport(self.h).decode()
+
+    def upload(self, words, n_bases):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        d = C.c_void_p()
+        _chk(lib().dnagpu_multi_dna_upload(self.h, w.ctypes.data_as(u64p), n_bases, C.byref(d)))
+        return d
+
+    def synth(self, seed, n_bases, motif_len=0):
+        d = C.c_void_p()
+        _chk(lib().dnagpu_multi_dna_synth(self.h, seed, n_bases, motif_len, C.byref(d)))
+        return d
+
+    def dna_free(self, d):
+        lib().dnagpu_multi_dna_free(self.h, d)
+
+    def count(self, mdna, k, first=0, count=None):
+        """-> [Hist per rank]; their ascending downloads concatenated in rank order are the global result"""
+        n_bases = int(lib().dnagpu_multi_dna_length(mdna))
+        total = kmer_count(n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        hs = (C.c_void_p * self.n)()
+        _chk(lib().dnagpu_count_multi(self.h, mdna, k, first, count, hs))
+        return [Hist(self.ranks[r], C.c_void_p(hs[r])) for r in range(self.n)]
+
+    def close(self):
+        if self.h:
+            lib().dnagpu_multi_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -511,7 +511,7 @@ extern "C" int dnagpu_dna_synth(dnagpu_ctx *ctx, uint64_t seed, uint64_t n_bases
     u64 nw = words_for(n_bases);
     u64 *d = nullptr;
     RC_TRY(pool_alloc_t(ctx, (size_t)std::max<u64>(nw, 1), &d));
-    hipError_t e = launch_synth(d, nw, n_bases, seed, motif_len, ctx->stream);
+    hipError_t e = launch_synth(d, 0, nw, n_bases, seed, motif_len, ctx->stream);
     if (e != hipSuccess) {
         pool_free(ctx, d);
         set_err("synth: %s", hipGetErrorString(e));
@@ -1598,6 +1598,321 @@ extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, in
     ps.release(tr.buf0);
     *dev_keys = tr.buf0;
     prof_end(ctx);
+    return DNAGPU_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU count from ONE process (what a PostgreSQL backend's glue can call): N contexts, one per
+// rank, the sequence resident as contiguous word chunks, one all-gather of the packed words (RCCL
+// over xGMI, or peer copies), then every rank counts the key range it owns in its own host thread.
+// Same algorithm and ownership rule as the process-per-GPU path of sharded.py (bench.py --gpus N).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <thread>
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        if (lib)
+            return true;
+        // loaded on demand: a single-GPU backend never maps RCCL
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib)
+                break;
+        }
+        if (!lib)
+            return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+}  // namespace
+
+struct dnagpu_multi {
+    int n;
+    std::vector<int> dev;
+    std::vector<dnagpu_ctx *> ctx;
+    bool rccl;
+    RcclApi api;
+    std::vector<ncclComm_t> comms;
+};
+
+struct dnagpu_multi_dna {
+    u64 n_bases, n_words, per;            // per = words per rank chunk; every rank's buffer holds per * n words
+    std::vector<u64 *> full;              // rank r: chunk r resident at full[r] + r * per; the rest is gather space
+    std::vector<dnagpu_dna *> view;       // full[r] as a dnagpu_dna of n_bases bases
+};
+
+extern "C" void dnagpu_multi_destroy(dnagpu_multi *m)
+{
+    if (!m)
+        return;
+    for (size_t r = 0; r < m->comms.size(); r++)
+        if (m->comms[r])
+            m->api.CommDestroy(m->comms[r]);
+    for (dnagpu_ctx *c : m->ctx)
+        dnagpu_destroy(c);
+    delete m;
+}
+
+extern "C" int dnagpu_multi_init(const int *devices, int n_gpus, int transport, dnagpu_multi **out)
+{
+    return guarded([&]() -> int {
+    if (!out || n_gpus < 1 || n_gpus > 64 || transport < DNAGPU_MULTI_AUTO || transport > DNAGPU_MULTI_COPY)
+        return DNAGPU_ERR_BAD_ARG;
+    *out = nullptr;
+    dnagpu_multi *m = new (std::nothrow) dnagpu_multi();
+    if (!m)
+        return DNAGPU_ERR_OOM;
+    m->n = n_gpus;
+    m->rccl = false;
+    bool distinct = true;
+    for (int r = 0; r < n_gpus; r++) {
+        const int d = devices ? devices[r] : r;
+        for (int q = 0; q < r; q++)
+            distinct = distinct && m->dev[q] != d;
+        m->dev.push_back(d);
+    }
+    for (int r = 0; r < n_gpus; r++) {
+        dnagpu_ctx *c = nullptr;
+        const int rc = dnagpu_init(m->dev[r], &c);
+        if (rc != DNAGPU_OK) {
+            dnagpu_multi_destroy(m);
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    // peer access for the copy transport and for RCCL's direct xGMI paths (failure is not fatal: copies stage)
+    for (int a = 0; a < n_gpus; a++)
+        for (int b = 0; b < n_gpus; b++)
+            if (m->dev[a] != m->dev[b]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]) == hipSuccess && can) {
+                    (void)hipSetDevice(m->dev[a]);
+                    const hipError_t e = hipDeviceEnablePeerAccess(m->dev[b], 0);
+                    if (e != hipSuccess)
+                        (void)hipGetLastError();      // already enabled, or not supported
+                }
+            }
+    const bool want_rccl = transport == DNAGPU_MULTI_RCCL || (transport == DNAGPU_MULTI_AUTO && n_gpus > 1 && distinct);
+    if (want_rccl) {
+        if (!distinct) {
+            set_err("RCCL transport needs %d distinct devices", n_gpus);
+            dnagpu_multi_destroy(m);
+            return DNAGPU_ERR_BAD_ARG;
+        }
+        if (!m->api.load()) {
+            if (transport == DNAGPU_MULTI_RCCL) {
+                set_err("librccl.so could not be loaded: %s", dlerror());
+                dnagpu_multi_destroy(m);
+                return DNAGPU_ERR_HIP;
+            }
+        } else {
+            m->comms.assign((size_t)n_gpus, nullptr);
+            const ncclResult_t nr = m->api.CommInitAll(m->comms.data(), n_gpus, m->dev.data());
+            if (nr != ncclSuccess) {
+                set_err("ncclCommInitAll: %s", m->api.GetErrorString(nr));
+                m->comms.clear();
+                dnagpu_multi_destroy(m);
+                return DNAGPU_ERR_HIP;
+            }
+            m->rccl = true;
+        }
+    }
+    *out = m;
+    return DNAGPU_OK;
+    });
+}
+
+extern "C" int dnagpu_multi_size(const dnagpu_multi *m) { return m ? m->n : 0; }
+extern "C" dnagpu_ctx *dnagpu_multi_ctx(dnagpu_multi *m, int rank)
+{
+    return (m && rank >= 0 && rank < m->n) ? m->ctx[(size_t)rank] : nullptr;
+}
+extern "C" const char *dnagpu_multi_transport(const dnagpu_multi *m) { return !m ? "" : (m->rccl ? "rccl" : "copy"); }
+
+extern "C" void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d)
+{
+    if (!d)
+        return;
+    for (size_t r = 0; r < d->view.size(); r++)
+        if (d->view[r])
+            dnagpu_dna_free(m ? m->ctx[r] : nullptr, d->view[r]);
+    if (m)
+        for (size_t r = 0; r < d->full.size(); r++)
+            pool_free(m->ctx[r], d->full[r]);
+    delete d;
+}
+
+// allocates every rank's buffer and wraps it; fill(r, w_lo, w_hi) makes rank r's own chunk resident
+template <typename Fill>
+static int multi_dna_make(dnagpu_multi *m, u64 n_bases, dnagpu_multi_dna **out, Fill &&fill)
+{
+    dnagpu_multi_dna *d = new (std::nothrow) dnagpu_multi_dna();
+    if (!d)
+        return DNAGPU_ERR_OOM;
+    d->n_bases = n_bases;
+    d->n_words = words_for(n_bases);
+    d->per = (d->n_words + (u64)m->n - 1) / (u64)m->n;
+    if (d->per == 0)
+        d->per = 1;
+    int rc = DNAGPU_OK;
+    for (int r = 0; r < m->n && rc == DNAGPU_OK; r++) {
+        dnagpu_ctx *c = m->ctx[(size_t)r];
+        hipError_t e = hipSetDevice(c->device);
+        u64 *buf = nullptr;
+        if (e == hipSuccess)
+            rc = pool_alloc_t(c, (size_t)(d->per * (u64)m->n), &buf);
+        if (e != hipSuccess || rc != DNAGPU_OK) {
+            if (e != hipSuccess) {
+                set_err("hipSetDevice: %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            }
+            break;
+        }
+        d->full.push_back(buf);
+        d->view.push_back(nullptr);
+        const u64 lo = std::min((u64)r * d->per, d->n_words), hi = std::min((u64)(r + 1) * d->per, d->n_words);
+        // gather space behind the last word of the sequence stays zero (never read as bases: n_words bounds every sweep)
+        e = hipMemsetAsync(buf + d->n_words, 0, (size_t)(d->per * (u64)m->n - d->n_words) * 8, c->stream);
+        if (e == hipSuccess)
+            e = fill(r, c, buf, lo, hi);
+        if (e != hipSuccess) {
+            set_err("multi dna: %s", hipGetErrorString(e));
+            rc = DNAGPU_ERR_HIP;
+            break;
+        }
+        rc = dnagpu_dna_wrap(c, buf, d->per * (u64)m->n, n_bases, &d->view[(size_t)r]);
+    }
+    for (int r = 0; r < m->n && rc == DNAGPU_OK; r++)
+        if (hipSetDevice(m->ctx[(size_t)r]->device) != hipSuccess || hipStreamSynchronize(m->ctx[(size_t)r]->stream) != hipSuccess)
+            rc = DNAGPU_ERR_HIP;
+    if (rc != DNAGPU_OK) {
+        dnagpu_multi_dna_free(m, d);
+        return rc;
+    }
+    *out = d;
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_multi_dna_upload(dnagpu_multi *m, const uint64_t *words, uint64_t n_bases, dnagpu_multi_dna **out)
+{
+    return guarded([&]() -> int {
+    if (!m || !out || (n_bases && !words))
+        return DNAGPU_ERR_BAD_ARG;
+    return multi_dna_make(m, n_bases, out, [&](int, dnagpu_ctx *c, u64 *buf, u64 lo, u64 hi) -> hipError_t {
+        if (hi <= lo)
+            return hipSuccess;
+        return hipMemcpyAsync(buf + lo, words + lo, (size_t)(hi - lo) * 8, hipMemcpyHostToDevice, c->stream);
+    });
+    });
+}
+
+extern "C" int dnagpu_multi_dna_synth(dnagpu_multi *m, uint64_t seed, uint64_t n_bases, uint64_t motif_len,
+                                      dnagpu_multi_dna **out)
+{
+    return guarded([&]() -> int {
+    if (!m || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    return multi_dna_make(m, n_bases, out, [&](int, dnagpu_ctx *c, u64 *buf, u64 lo, u64 hi) -> hipError_t {
+        return launch_synth(buf, lo, hi, n_bases, seed, motif_len, c->stream);
+    });
+    });
+}
+
+extern "C" uint64_t dnagpu_multi_dna_length(const dnagpu_multi_dna *d) { return d ? d->n_bases : 0; }
+
+// every rank's buffer receives the other ranks' chunks, ordered on each rank's own stream
+static int multi_gather(dnagpu_multi *m, const dnagpu_multi_dna *d)
+{
+    if (m->n == 1)
+        return DNAGPU_OK;
+    const size_t per_bytes = (size_t)d->per * 8;
+    if (m->rccl) {
+        ncclResult_t nr = m->api.GroupStart();
+        for (int r = 0; r < m->n && nr == ncclSuccess; r++)     // in place: send = recv + rank * count
+            nr = m->api.AllGather(d->full[(size_t)r] + (u64)r * d->per, d->full[(size_t)r], (size_t)d->per, ncclUint64,
+                                  m->comms[(size_t)r], m->ctx[(size_t)r]->stream);
+        const ncclResult_t ne = m->api.GroupEnd();
+        if (nr != ncclSuccess || ne != ncclSuccess) {
+            set_err("ncclAllGather: %s", m->api.GetErrorString(nr != ncclSuccess ? nr : ne));
+            return DNAGPU_ERR_HIP;
+        }
+        return DNAGPU_OK;
+    }
+    for (int dst = 0; dst < m->n; dst++) {
+        dnagpu_ctx *c = m->ctx[(size_t)dst];
+        HIP_TRY(hipSetDevice(c->device));
+        for (int q = 1; q < m->n; q++) {                          // start at the neighbour: spreads the link load
+            const int src = (dst + q) % m->n;
+            u64 *to = d->full[(size_t)dst] + (u64)src * d->per;
+            const u64 *from = d->full[(size_t)src] + (u64)src * d->per;
+            if (m->dev[(size_t)src] == m->dev[(size_t)dst])
+                HIP_TRY(hipMemcpyAsync(to, from, per_bytes, hipMemcpyDeviceToDevice, c->stream));
+            else
+                HIP_TRY(hipMemcpyPeerAsync(to, m->dev[(size_t)dst], from, m->dev[(size_t)src], per_bytes, c->stream));
+        }
+    }
+    return DNAGPU_OK;
+}
+
+extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
+                                  dnagpu_hist **hists)
+{
+    return guarded([&]() -> int {
+    if (!m || !dna || !hists || (int)dna->view.size() != m->n)
+        return DNAGPU_ERR_BAD_ARG;
+    for (int r = 0; r < m->n; r++)
+        hists[r] = nullptr;
+    RC_TRY(check_range(dna->view[0], k, first, count));
+    RC_TRY(multi_gather(m, dna));
+    // one host thread per rank: the level loop of a count reads counters back between levels, so the ranks
+    // only run concurrently when each is driven by its own thread (device selection is per thread)
+    std::vector<int> rcs((size_t)m->n, DNAGPU_OK);
+    std::vector<std::string> errs((size_t)m->n);
+    auto work = [&](int r) {
+        rcs[(size_t)r] = dnagpu_count_kmers_owned(m->ctx[(size_t)r], dna->view[(size_t)r], k, first, count, r, m->n,
+                                                 &hists[r]);
+        if (rcs[(size_t)r] != DNAGPU_OK)
+            errs[(size_t)r] = dnagpu_last_error();                // the error text is per thread
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < m->n; r++)
+        th.emplace_back(work, r);
+    work(0);
+    for (std::thread &t : th)
+        t.join();
+    for (int r = 0; r < m->n; r++)
+        if (rcs[(size_t)r] != DNAGPU_OK) {
+            set_err("rank %d: %s", r, errs[(size_t)r].c_str());
+            for (int q = 0; q < m->n; q++) {
+                dnagpu_hist_free(m->ctx[(size_t)q], hists[q]);
+                hists[q] = nullptr;
+            }
+            return rcs[(size_t)r];
+        }
     return DNAGPU_OK;
     });
 }

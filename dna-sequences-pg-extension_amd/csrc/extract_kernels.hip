@@ -11,11 +11,12 @@ namespace dnagpu {
 // ------------------------------------------------------------------------------------------------
 // synthetic packed dna: word w = splitmix64(seed + w); repeat variant tiles the first motif_len
 // bases over the second half.  Mirrors oracle/kmer_oracle.c orc_synth_words{,_repeat}.
-__global__ __launch_bounds__(256) void synth_kernel(u64 *__restrict__ words, u64 n_words, u64 n_bases,
+// words[w] for w in [w_begin, w_end): a rank of the multi-GPU path generates only its own word chunk
+__global__ __launch_bounds__(256) void synth_kernel(u64 *__restrict__ words, u64 w_begin, u64 w_end, u64 n_bases,
                                                     u64 seed, u64 motif_len)
 {
-    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words)
+    u64 w = w_begin + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= w_end)
         return;
     u64 v;
     u64 half = n_bases / 2;
@@ -39,12 +40,12 @@ __global__ __launch_bounds__(256) void synth_kernel(u64 *__restrict__ words, u64
     words[w] = v;
 }
 
-hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s)
+hipError_t launch_synth(u64 *words, u64 w_begin, u64 w_end, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s)
 {
-    if (n_words == 0)
+    if (w_end <= w_begin)
         return hipSuccess;
-    unsigned grid = (unsigned)((n_words + 255) / 256);
-    hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(256), 0, s, words, n_words, n_bases, seed, motif_len);
+    unsigned grid = (unsigned)((w_end - w_begin + 255) / 256);
+    hipLaunchKernelGGL(synth_kernel, dim3(grid), dim3(256), 0, s, words, w_begin, w_end, n_bases, seed, motif_len);
     return hipGetLastError();
 }
 

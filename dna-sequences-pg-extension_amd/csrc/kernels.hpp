@@ -9,7 +9,8 @@
 namespace dnagpu {
 
 // ---------------------------------------------------------------- extract_kernels.hip
-hipError_t launch_synth(u64 *words, u64 n_words, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s);
+// words[w] of the synthetic sequence of n_bases bases for w in [w_begin, w_end) (words = the sequence's word 0)
+hipError_t launch_synth(u64 *words, u64 w_begin, u64 w_end, u64 n_bases, u64 seed, u64 motif_len, hipStream_t s);
 hipError_t launch_extract(const u64 *words, u64 n_words, u64 first, u64 count, int k, u64 *out_keys,
                           hipStream_t s);
 

@@ -73,6 +73,8 @@ def lib():
         L.kmer_recv.restype = C.c_bool
         L.kmer_recv.argtypes = [C.c_char_p, C.POINTER(_Kmer)]
         L.dna_glue_shutdown.restype = None
+        L.dna_glue_set_gpus.restype = None
+        L.dna_glue_set_gpus.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
         _LIB = L
     return _LIB
 
@@ -218,6 +220,12 @@ def generate_kmers_where(d, k, op, rhs):
     if op == "@>":
         return _drain(lib().generate_kmers_where_begin(d.p, k, b"@", None, C.byref(rhs.c)))
     return _drain(lib().generate_kmers_where_begin(d.p, k, b"=" if op == "=" else b"^", C.byref(rhs.c), None))
+
+
+def set_gpus(devices, transport=0):
+    """count_kmers shards over these HIP devices from now on (dna_glue_set_gpus); [0] = single GPU"""
+    n = len(devices)
+    lib().dna_glue_set_gpus(n, (C.c_int * n)(*devices), transport)
 
 
 def count_kmers(d, k):

@@ -26,8 +26,11 @@ static void ereport_error(const char *fmt, ...)
 const char *dna_glue_errmsg(void) { return g_msg; }
 void dna_glue_set_device(int device) { g_device = device; }
 
+static void multi_shutdown(void);
+
 void dna_glue_shutdown(void)
 {
+    multi_shutdown();
     if (g_ctx) {
         dnagpu_destroy(g_ctx);
         g_ctx = NULL;
@@ -490,22 +493,56 @@ void generate_kmers_end(GenerateKmers *g)
 /* ------------------------------------------------------------------ count_kmers */
 
 #define CK_WINDOW ((uint64_t)1 << 21)
+#define CK_MAX_RANKS 64
 
+/* one histogram per rank (one rank unless dna_glue_set_gpus asked for more); rank order = ascending key ranges */
 struct CountKmers {
     int k;
-    dnagpu_hist *hist;
-    uint64_t distinct, next, win_first, win_count;
+    int n_ranks, rank;                       /* rank = the histogram rows are being served from */
+    dnagpu_hist *hist[CK_MAX_RANKS];
+    dnagpu_ctx *hctx[CK_MAX_RANKS];
+    uint64_t rank_distinct, next, win_first, win_count;   /* cursor inside hist[rank] */
+    uint64_t distinct;
     uint64_t *keys, *counts;
     uint64_t total, unique;
 };
+
+/* multi-GPU configuration of this backend: count_kmers shards over these devices (dnagpu_count_multi) */
+static int g_n_gpus = 1, g_transport = DNAGPU_MULTI_AUTO;
+static int g_gpu_list[CK_MAX_RANKS];
+static dnagpu_multi *g_multi;
+
+void dna_glue_set_gpus(int n_gpus, const int *devices, int transport)
+{
+    if (g_multi) {
+        dnagpu_multi_destroy(g_multi);
+        g_multi = NULL;
+    }
+    g_n_gpus = n_gpus < 1 ? 1 : (n_gpus > CK_MAX_RANKS ? CK_MAX_RANKS : n_gpus);
+    for (int r = 0; r < g_n_gpus; r++)
+        g_gpu_list[r] = devices ? devices[r] : r;
+    g_transport = transport;
+}
+
+static void multi_shutdown(void)
+{
+    if (g_multi) {
+        dnagpu_multi_destroy(g_multi);
+        g_multi = NULL;
+    }
+}
+
+static dnagpu_multi *multi(void)
+{
+    if (!g_multi && !gpu_ok(dnagpu_multi_init(g_gpu_list, g_n_gpus, g_transport, &g_multi)))
+        return NULL;
+    return g_multi;
+}
 
 CountKmers *count_kmers_begin(Dna *dna, int k)
 {
     uint64_t n_rows = 0;
     if (!gpu_ok(dnagpu_kmer_count(dna->length, k, &n_rows)))
-        return NULL;
-    dnagpu_dna *d = device_dna(dna);
-    if (!d)
         return NULL;
     CountKmers *c = (CountKmers *)calloc(1, sizeof *c);
     if (!c) {
@@ -513,16 +550,43 @@ CountKmers *count_kmers_begin(Dna *dna, int k)
         return NULL;
     }
     c->k = k;
-    uint64_t checksum;
-    if (!gpu_ok(dnagpu_count_kmers(g_ctx, d, k, 0, n_rows, &c->hist)) ||
-        !gpu_ok(dnagpu_hist_summary(g_ctx, c->hist, &c->total, &c->unique, &checksum))) {
+    bool ok;
+    if (g_n_gpus > 1) {
+        /* the sequence goes to the ranks as contiguous word chunks; one all-gather + per-rank owner counts */
+        dnagpu_multi *m = multi();
+        dnagpu_multi_dna *md = NULL;
+        ok = m && gpu_ok(dnagpu_multi_dna_upload(m, dna->bit_sequence, dna->length, &md));
+        if (ok) {
+            c->n_ranks = g_n_gpus;
+            for (int r = 0; r < c->n_ranks; r++)
+                c->hctx[r] = dnagpu_multi_ctx(m, r);
+            ok = gpu_ok(dnagpu_count_multi(m, md, k, 0, n_rows, c->hist));
+            dnagpu_multi_dna_free(m, md);
+        }
+    } else {
+        dnagpu_dna *d = device_dna(dna);
+        ok = d != NULL;
+        if (ok) {
+            c->n_ranks = 1;
+            c->hctx[0] = g_ctx;
+            ok = gpu_ok(dnagpu_count_kmers(g_ctx, d, k, 0, n_rows, &c->hist[0]));
+        }
+    }
+    for (int r = 0; ok && r < c->n_ranks; r++) {
+        uint64_t t = 0, u = 0, checksum;
+        ok = gpu_ok(dnagpu_hist_summary(c->hctx[r], c->hist[r], &t, &u, &checksum));
+        c->total += t;
+        c->unique += u;
+        c->distinct += dnagpu_hist_distinct(c->hist[r]);
+    }
+    if (!ok) {
         count_kmers_end(c);
         return NULL;
     }
-    c->distinct = dnagpu_hist_distinct(c->hist);
-    uint64_t w = c->distinct < CK_WINDOW ? (c->distinct ? c->distinct : 1) : CK_WINDOW;
-    c->keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)w);
-    c->counts = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)w);
+    c->rank = 0;
+    c->rank_distinct = dnagpu_hist_distinct(c->hist[0]);
+    c->keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)CK_WINDOW);
+    c->counts = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)CK_WINDOW);
     if (!c->keys || !c->counts) {
         ereport_error("out of memory");
         count_kmers_end(c);
@@ -533,11 +597,16 @@ CountKmers *count_kmers_begin(Dna *dna, int k)
 
 bool count_kmers_next(CountKmers *c, Kmer *kmer, int64_t *count)
 {
-    if (c->next >= c->distinct)
-        return false;
+    while (c->next >= c->rank_distinct) {            /* this rank's key range is served: on to the next one */
+        if (c->rank + 1 >= c->n_ranks)
+            return false;
+        c->rank++;
+        c->rank_distinct = dnagpu_hist_distinct(c->hist[c->rank]);
+        c->next = c->win_first = c->win_count = 0;
+    }
     if (c->next >= c->win_first + c->win_count) {
-        uint64_t n = c->distinct - c->next < CK_WINDOW ? c->distinct - c->next : CK_WINDOW;
-        if (!gpu_ok(dnagpu_hist_download(g_ctx, c->hist, c->next, n, c->keys, c->counts)))
+        uint64_t n = c->rank_distinct - c->next < CK_WINDOW ? c->rank_distinct - c->next : CK_WINDOW;
+        if (!gpu_ok(dnagpu_hist_download(c->hctx[c->rank], c->hist[c->rank], c->next, n, c->keys, c->counts)))
             return false;
         c->win_first = c->next;
         c->win_count = n;
@@ -560,8 +629,9 @@ void count_kmers_end(CountKmers *c)
 {
     if (!c)
         return;
-    if (c->hist)
-        dnagpu_hist_free(g_ctx, c->hist);
+    for (int r = 0; r < c->n_ranks; r++)
+        if (c->hist[r])
+            dnagpu_hist_free(c->hctx[r], c->hist[r]);
     free(c->keys);
     free(c->counts);
     free(c);

@@ -47,6 +47,10 @@ typedef struct Qkmer {
 const char *dna_glue_errmsg(void);      /* text of the last "ereport(ERROR)" on this thread */
 /* Device used by this process (default 0); must be called before the first GPU call. */
 void dna_glue_set_device(int device);
+/* GPUs count_kmers shards over (default 1 = the single device above): ranks on HIP devices devices[0..n)
+ * (NULL = 0..n-1; a device may repeat, which rehearses the path on a one-GPU box) and the exchange
+ * transport (DNAGPU_MULTI_AUTO / _RCCL / _COPY of include/dnagpu.h).  Takes effect at the next count. */
+void dna_glue_set_gpus(int n_gpus, const int *devices, int transport);
 /* Releases the GPU context (end of backend). */
 void dna_glue_shutdown(void);
 

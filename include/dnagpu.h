@@ -228,6 +228,42 @@ void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr);
 int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint64_t bytes, void *host);
 int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint64_t bytes);
 
+/* ---- multi-GPU count from one process (the call a PostgreSQL backend's glue makes; SURVEY.md 8(b)
+ * dnagpu_count_multi) ----------------------------------------------------------------------------------
+ * A dnagpu_multi holds one context per rank (rank r on HIP device devices[r]; devices == NULL means 0..n-1;
+ * the same device may appear more than once, which is how the path is rehearsed on a one-GPU box) and the
+ * exchange transport: DNAGPU_MULTI_RCCL = ncclCommInitAll + ncclAllGather over xGMI (librccl.so is loaded on
+ * demand; needs distinct devices), DNAGPU_MULTI_COPY = peer copies, DNAGPU_MULTI_AUTO = RCCL when n_gpus > 1
+ * distinct devices and the library loads, else copies. */
+typedef struct dnagpu_multi dnagpu_multi;
+#define DNAGPU_MULTI_AUTO 0
+#define DNAGPU_MULTI_RCCL 1
+#define DNAGPU_MULTI_COPY 2
+int dnagpu_multi_init(const int *devices, int n_gpus, int transport, dnagpu_multi **out);
+void dnagpu_multi_destroy(dnagpu_multi *m);
+int dnagpu_multi_size(const dnagpu_multi *m);
+dnagpu_ctx *dnagpu_multi_ctx(dnagpu_multi *m, int rank);
+const char *dnagpu_multi_transport(const dnagpu_multi *m);   /* "rccl" or "copy" */
+
+/* The packed sequence sharded by contiguous word chunk: rank r is resident with words
+ * [r*per, (r+1)*per), per = ceil(ceil(n_bases/32) / n).  upload: from the host words of dna->bit_sequence
+ * (dna.c:45-46); synth: every rank generates its own chunk (dnagpu_dna_synth's sequence). */
+typedef struct dnagpu_multi_dna dnagpu_multi_dna;
+int dnagpu_multi_dna_upload(dnagpu_multi *m, const uint64_t *words, uint64_t n_bases, dnagpu_multi_dna **out);
+int dnagpu_multi_dna_synth(dnagpu_multi *m, uint64_t seed, uint64_t n_bases, uint64_t motif_len,
+                           dnagpu_multi_dna **out);
+uint64_t dnagpu_multi_dna_length(const dnagpu_multi_dna *d);
+void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d);
+
+/* GROUP BY kmer, count(*) over rows [first, first+count) of generate_kmers(dna, k) on all ranks: one
+ * all-gather of the packed chunks (2 bits per base), then rank r counts the keys it owns (owner rule of
+ * dnagpu_count_kmers_owned) in its own host thread.  hists[r] (n entries, caller's array) = rank r's
+ * histogram, living on rank r's device; the ranks' ascending downloads concatenated in rank order are the
+ * global result in ascending key order, sum of dnagpu_hist_total = count.  Free each with
+ * dnagpu_hist_free(dnagpu_multi_ctx(m, r), hists[r]). */
+int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
+                       dnagpu_hist **hists);
+
 /* ---- batched operators over arrays of keys (bulk scans of stored kmer columns) -------------- */
 
 /* kmer_hash (dna.c:722-735): PostgreSQL hash_any over the 8 bytes of bit_sequence. n keys in,

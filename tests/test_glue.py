@@ -132,6 +132,33 @@ def test_sql_group_by_count(g, ref_vectors):
 
 
 @pytest.mark.gpu
+def test_sql_group_by_count_multi_gpu(g, ref_vectors):
+    """the same statements with count_kmers sharded over several ranks through dnagpu_count_multi (one process;
+    the ranks share device 0 on a one-GPU box): same groups, same totals, rows in ascending key order"""
+    import numpy as np
+    import oracle as orc
+    try:
+        for n_ranks in (2, 3, 8):
+            g.set_gpus([0] * n_ranks, 2)                                     # DNAGPU_MULTI_COPY
+            for v in ref_vectors["count"]:                                   # test.sql:95-104
+                rows, _ = g.count_kmers(v["dna"], v["k"])
+                assert {str(k): c for k, c in rows} == v["groups"]
+            for v in ref_vectors["summary"]:                                 # test.sql:107-119
+                _, totals = g.count_kmers(v["dna"], v["k"])
+                assert totals == (v["total"], v["distinct"], v["unique"])
+        g.set_gpus([0, 0, 0], 2)
+        n, k = 200_003, 12
+        words = orc.synth_words(77, n)
+        rows, totals = g.count_kmers(orc.dna_decode(words, n), k)
+        ok, oc = orc.count_kmers(words, n, k)
+        assert [r[0].c.bit_sequence for r in rows] == [int(x) for x in ok]
+        assert [r[1] for r in rows] == [int(x) for x in oc]
+        assert totals[0] == n - k + 1 and totals[1] == len(ok)
+    finally:
+        g.set_gpus([0])
+
+
+@pytest.mark.gpu
 def test_srf_windows_cross_refills(g):
     # more rows than one GPU window (4 Mi rows): rows keep position order across refills
     import numpy as np

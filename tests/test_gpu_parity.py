@@ -701,6 +701,48 @@ def test_count_kmers_owned(ctx, n_owners):
         d.free()
 
 
+# ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+def test_count_multi_one_process(pkg, n_ranks):
+    """dnagpu_count_multi: N ranks driven from one process (every rank mapped to device 0 here, copy transport;
+    chunk residency, the gather of the packed chunks and the per-rank owner counts are the product code).  The
+    ranks' ascending downloads concatenated in rank order == the oracle's sorted histogram."""
+    n, seed = 3_000_017, 0xD2A0003
+    words = orc.synth_words(seed, n)
+    with pkg.Multi([0] * n_ranks, pkg.MULTI_COPY) as m:
+        assert m.transport == "copy"
+        for make in ("synth", "upload"):
+            d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
+            for k, first, count in ((31, 0, None), (21, 1000, 2_000_000), (8, 0, None), (3, 5, 1_000_000)):
+                ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False)[first:None if count is None else first + count])
+                hs = m.count(d, k, first, count)
+                gk = np.concatenate([h.download()[0] for h in hs])
+                gc = np.concatenate([h.download()[1] for h in hs])
+                assert sum(h.total for h in hs) == int(oc.sum())
+                assert_same(gk, ok, f"multi {n_ranks} ranks ({make}) k={k} keys")
+                assert_same(gc, oc, f"multi {n_ranks} ranks ({make}) k={k} counts")
+                for h in hs:
+                    h.free()
+            m.dna_free(d)
+
+
+def test_count_multi_rccl_one_rank(pkg):
+    """the RCCL transport (librccl.so loaded on demand, ncclCommInitAll) with the one device a test box has"""
+    n, k, seed = 1_000_003, 31, 0xD2A0002
+    words = orc.synth_words(seed, n)
+    with pkg.Multi([0], pkg.MULTI_RCCL) as m:
+        assert m.transport == "rccl"
+        d = m.synth(seed, n)
+        hs = m.count(d, k)
+        ok, oc = orc.count_kmers(words, n, k)
+        check_hist(hs[0], ok, oc, "multi rccl one rank")
+        hs[0].free()
+        m.dna_free(d)
+    with pytest.raises(pkg.DnaGpuError):
+        pkg.Multi([0, 0], pkg.MULTI_RCCL)          # RCCL needs distinct devices
+
+
 # ------------------------------------------------------------------ BASELINE.json sizes (properties)
 
 def test_config2_k21_100M_against_oracle_summary(ctx):
