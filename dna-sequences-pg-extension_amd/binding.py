@@ -89,6 +89,8 @@ def lib():
     L.dnagpu_generate_kmers_filtered.argtypes = [vp, vp, C.c_int, C.POINTER(_FilterC), C.c_uint64,
                                                  C.c_uint64, vp, vp, C.c_uint64, u64p, C.c_int]
     L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_count_kmers_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_hist_is_sorted.argtypes = [vp]
     L.dnagpu_count_keys.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.dnagpu_count_kmers_owned.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
     L.dnagpu_count_keys_in_range.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
@@ -228,6 +230,10 @@ class Hist:
     @property
     def device_counts(self):
         return lib().dnagpu_hist_device_counts(self.h)
+
+    @property
+    def is_sorted(self):
+        return bool(lib().dnagpu_hist_is_sorted(self.h))
 
     def download(self, first=0, count=None):
         if count is None:
@@ -405,6 +411,15 @@ class Context:
             count = max(total - first, 0)
         h = C.c_void_p()
         _chk(lib().dnagpu_count_kmers(self.h, dna.h, k, first, count, C.byref(h)))
+        return Hist(self, h)
+
+    def count_kmers_unordered(self, dna, k, first=0, count=None):
+        """same groups, order unspecified (as PostgreSQL's GROUP BY): long k-mers go through super-k-mer partitioning"""
+        total = kmer_count(dna.n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_kmers_unordered(self.h, dna.h, k, first, count, C.byref(h)))
         return Hist(self, h)
 
     def count_kmers_owned(self, dna, k, owner, n_owners, first=0, count=None):

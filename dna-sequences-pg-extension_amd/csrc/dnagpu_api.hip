@@ -133,6 +133,7 @@ struct dnagpu_hist {
     u32 *seg_cnt;
     u32 *seg_pre;     // exclusive scan of seg_cnt, built on first ordered download
     u32 n_segs;
+    bool sorted;      // the segments are consecutive key ranges (true unless the super-k-mer engine made them)
 };
 
 // DNAGPU_DEBUG_POISON_POOL: no work buffer starts out zeroed (fresh hipMalloc memory) or holding a
@@ -1082,9 +1083,12 @@ struct TreeResult {
 // Runs levels until every node is a leaf (force_bits == 0), or exactly one forced level of
 // `force_bits` bits on the root (force_bits > 0).  dna != null: root over the packed sequence
 // (keys land in buf0, allocated here); else root over keys_in (used as buf0).
+// init_nodes != null: the levels start at `start_level` from that node list over keys_in (pool memory of `ps`; the
+// nodes' key ranges need not share key bits: the super-k-mer engine enters here with its bucket nodes)
 static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k,
                     u64 *keys_in, int force_bits, TreeResult *res, int fixed_bits = 0, u64 fixed_prefix = 0,
-                    bool single_level = true, u32 flt_lo = 0, u32 flt_span = ~0u, u32 flt_tb = 0)
+                    bool single_level = true, u32 flt_lo = 0, u32 flt_span = ~0u, u32 flt_tb = 0,
+                    Node *init_nodes = nullptr, u32 init_n = 0, int start_level = 0)
 {
     hipStream_t st = ctx->stream;
     u64 *buf0 = keys_in, *buf1 = nullptr;
@@ -1105,11 +1109,13 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
             root.meta |= NODE_BUF;          // children of the dna root go to buffer 0
         }
     }
-    Node *cur = nullptr;
-    RC_TRY(ps.alloc(1, &cur));
-    HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
-    u32 n_nodes = 1, n_big = 0, n_small = 0, n_tiny = 0;
+    Node *cur = init_nodes;
+    u32 n_nodes = init_nodes ? init_n : 1u, n_big = 0, n_small = 0, n_tiny = 0;
+    if (!init_nodes) {
+        RC_TRY(ps.alloc(1, &cur));
+        HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
+    }
     u32 n_nonempty = 1;           // nodes of the current level that uniform data would fill (all, or an owner's share)
 
     static u64 chunk_target = 0;                 // chunks per level (work units of the hist/scatter kernels)
@@ -1122,7 +1128,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     u32 chunk_len = (u32)std::max<u64>(4 * (u64)scatter_tile_keys(), (n + chunk_target - 1) / chunk_target);
     chunk_len = (chunk_len + scatter_tile_keys() - 1) / scatter_tile_keys() * scatter_tile_keys();
 
-    for (int level = 0;; level++) {
+    for (int level = start_level;; level++) {
         const int li = std::min(level, 4);
         prof_mark(ctx, LEVEL_PLAN_NAMES[li]);
         u32 *outc = nullptr, *nch = nullptr, *scan_tmp = nullptr;
@@ -1224,12 +1230,166 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     return DNAGPU_OK;
 }
 
+// ---- super-k-mer engine (superkmer_kernels.hip): the partition passes move 16-byte records of ~9 k-mers
+// instead of 8-byte keys.  On success *keys / *nodes / *n_nodes (pool memory of `ps`) are bucket nodes of about
+// SK_LEAF_MEAN keys over a key buffer: the ordinary tree continues from them at level 2.
+// DNAGPU_SK_SKEWED: a bucket is too heavy for the one workgroup that expands it (low-complexity input): the
+// caller counts with the ordinary tree instead, which has the skew paths.
+constexpr int DNAGPU_SK_SKEWED = -1;
+constexpr u64 SK_LEAF_MEAN = 3800;               // planned keys per final node (LEAF_CAP 6144: > 7 sigma above)
+constexpr u64 SK_MID_LIMIT = (u64)1 << 21;       // most k-mers one mid bucket may hold (planned: 16 x SK_LEAF_MEAN)
+
+struct SkLevel {                                 // what one forced partition level leaves behind
+    Node *next;
+    u32 n_next;
+    u32 *hist, *tot;
+    Chunk *chunks;
+    u32 n_chunks;
+};
+
+// plan (forced split on `bits` bits) + chunk list + histogram tables of one level over `cur`
+static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes, int bits, u32 chunk_len, SkLevel *lv)
+{
+    hipStream_t st = ctx->stream;
+    u32 *outc = nullptr, *nch = nullptr, *scan_tmp = nullptr;
+    LevelCounters *ctr = nullptr;
+    RC_TRY(ps.alloc(n_nodes, &outc));
+    RC_TRY(ps.alloc(n_nodes, &nch));
+    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
+    RC_TRY(ps.alloc(1, &ctr));
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(LevelCounters), st));
+    HIP_TRY(launch_plan(cur, n_nodes, -bits, chunk_len, outc, nch, ctr, st));
+    HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
+    HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
+    LevelCounters hc;
+    HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    lv->n_next = hc.n_next;
+    lv->n_chunks = hc.n_chunks;
+    RC_TRY(ps.alloc(std::max<u32>(hc.n_chunks, 1), &lv->chunks));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(hc.n_chunks, 1) * ROW_STRIDE, &lv->hist));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(hc.n_chunks, 1) * ROW_STRIDE, &lv->tot));
+    RC_TRY(ps.alloc(std::max<u32>(hc.n_next, 1), &lv->next));
+    HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, lv->chunks, st));
+    ps.free_now(scan_tmp);
+    // (outc / nch / ctr stay allocated until the scope ends: fill_chunks reads them asynchronously)
+    (void)hc;
+    return DNAGPU_OK;
+}
+
+static int run_sk(dnagpu_ctx *ctx, PoolScope &ps_out, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 **keys,
+                  Node **nodes, u32 *n_nodes)
+{
+    hipStream_t st = ctx->stream;
+    PoolScope ps(ctx);                           // everything but the keys and the final node list dies with this scope
+    // geometry: final nodes of ~SK_LEAF_MEAN keys = 16 per mid bucket; mid buckets = C0 coarse x 2^b1
+    const u64 n_final = std::max<u64>(n / SK_LEAF_MEAN, 16);
+    const u64 n_mid = (n_final + 15) / 16;
+    int b1 = 1;
+    while (b1 < MAX_SPLIT_BITS && ((u64)1 << b1) < n_mid)
+        b1++;
+    const u32 c0n = (u32)std::min<u64>((n_mid + ((u64)1 << b1) - 1) >> b1, (u64)1 << MAX_SPLIT_BITS);
+    int r0bits = 1;
+    while ((1u << r0bits) < c0n)
+        r0bits++;
+
+    // ---- level 0: the packed sequence -> records in c0n coarse buckets
+    Node root;
+    memset(&root, 0, sizeof root);
+    root.len = (u32)n;
+    root.meta = 32;                              // "remaining bits" of the bucket digits: r0bits + b1 <= 20 of them are split on
+    Node *cur = nullptr;
+    RC_TRY(ps.alloc(1, &cur));
+    HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const u64 tile = (u64)sk_tile_rows();
+    u64 chunk_rows = std::max<u64>(4 * tile, (n + 4095) / 4096);
+    chunk_rows = (chunk_rows + tile - 1) / tile * tile;
+    prof_mark(ctx, "sk_plan0");
+    SkLevel l0;
+    RC_TRY(sk_level_begin(ctx, ps, cur, 1, r0bits, (u32)chunk_rows, &l0));
+    prof_mark(ctx, "sk_hist0");
+    HIP_TRY(launch_sk_level0(false, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
+                             l0.hist, nullptr, nullptr, st));
+    prof_mark(ctx, "sk_prefix0");
+    HIP_TRY(launch_level_prefix(cur, l0.chunks, l0.n_chunks, 1, (u32)chunk_rows, l0.hist, l0.tot, st));
+    HIP_TRY(launch_level_children(cur, 1, l0.tot, l0.next, nullptr, nullptr, nullptr, 0, st));
+    std::vector<Node> kids(l0.n_next);
+    HIP_TRY(hipMemcpyAsync(kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    u64 n_recs = 0;
+    for (const Node &c : kids)
+        n_recs += c.len;
+    if (n_recs > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    void *rec0 = nullptr, *rec1 = nullptr;
+    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec0));
+    ps.ptrs.push_back(rec0);
+    prof_mark(ctx, "sk_scatter0");
+    HIP_TRY(launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
+                             l0.hist, l0.tot, rec0, st));
+
+    // ---- level 1: records of every coarse bucket -> 2^b1 mid buckets; k-mers per mid bucket on the way
+    u64 chunk_recs = std::max<u64>(4 * 8192, (n_recs + 4095) / 4096);
+    chunk_recs = (chunk_recs + 8191) / 8192 * 8192;
+    prof_mark(ctx, "sk_plan1");
+    SkLevel l1;
+    RC_TRY(sk_level_begin(ctx, ps, l0.next, l0.n_next, b1, (u32)chunk_recs, &l1));
+    u32 *kcount = nullptr;
+    RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &kcount));
+    HIP_TRY(hipMemsetAsync(kcount, 0, (size_t)std::max<u32>(l1.n_next, 1) * sizeof(u32), st));
+    prof_mark(ctx, "sk_hist1");
+    HIP_TRY(launch_sk_hist1(l0.next, l1.chunks, l1.n_chunks, rec0, l1.hist, kcount, st));
+    prof_mark(ctx, "sk_prefix1");
+    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, c0n, (u32)chunk_recs, l1.hist, l1.tot, st));
+    HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
+    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
+    ps.ptrs.push_back(rec1);
+    prof_mark(ctx, "sk_scatter1");
+    HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
+
+    // ---- k-mers per mid bucket -> key ranges (host: the list is short), skew check
+    std::vector<u32> kc(l1.n_next), kb(l1.n_next);
+    HIP_TRY(hipMemcpyAsync(kc.data(), kcount, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    u64 run = 0, heaviest = 0;
+    for (u32 i = 0; i < l1.n_next; i++) {
+        kb[i] = (u32)run;
+        run += kc[i];
+        heaviest = std::max<u64>(heaviest, kc[i]);
+    }
+    if (run != n) {
+        set_err("super-k-mer partition lost rows: %llu of %llu", (unsigned long long)run, (unsigned long long)n);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    if (heaviest > SK_MID_LIMIT)
+        return DNAGPU_SK_SKEWED;
+    u32 *key_base = nullptr;
+    RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &key_base));
+    HIP_TRY(hipMemcpyAsync(key_base, kb.data(), (size_t)l1.n_next * sizeof(u32), hipMemcpyHostToDevice, st));
+    u64 *kbuf = nullptr;
+    Node *fin = nullptr;
+    RC_TRY(ps_out.alloc((size_t)n, &kbuf));
+    RC_TRY(ps_out.alloc((size_t)l1.n_next * 16, &fin));
+    prof_mark(ctx, "sk_expand");
+    HIP_TRY(launch_sk_expand(l1.next, l1.n_next, rec1, key_base, k, kbuf, fin, st));
+    HIP_TRY(hipStreamSynchronize(st));           // kb / kc are host vectors
+    *keys = kbuf;
+    *nodes = fin;
+    *n_nodes = l1.n_next * 16;
+    return DNAGPU_OK;
+}
+
+// any_order: the caller does not need ascending keys across the whole result (dnagpu_count_kmers_unordered): long
+// k-mers of long sequences then go through the super-k-mer engine
+constexpr u64 SK_MIN_ROWS = (u64)1 << 22;
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
-                      dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1)
+                      dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
+                      bool any_order = false)
 {
     if (n > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
-    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, n, nullptr, nullptr, nullptr, 0};
+    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, n, nullptr, nullptr, nullptr, 0, true};
     if (!h)
         return DNAGPU_ERR_OOM;
     if (n == 0) {
@@ -1238,6 +1398,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     }
     prof_begin(ctx);
     int rc;
+    bool sorted = true;                          // segments in ascending key order (false: bucket order of the super-k-mer engine)
     if (dna && n_owners == 1 && fixed_bits == 0 && 2 * k <= dense_max_bits() && n > (u64)LEAF_CAP &&
         n >= ((u64)(2 * k > 16 ? 64 : 4) << (2 * k))) {   // (enough rows to pay for the passes and for compacting the table)
         // short k-mers: the histogram is a table of at most 262,144 counters filled straight from the
@@ -1308,7 +1469,22 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             }
             rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo, span, tb);
         } else {
-            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
+            bool done = false;
+            if (any_order && dna && fixed_bits == 0 && k >= sk_min_k() && n >= SK_MIN_ROWS) {
+                u64 *sk_keys = nullptr;
+                Node *sk_nodes = nullptr;
+                u32 sk_n = 0;
+                rc = run_sk(ctx, ps, dna, first, n, k, &sk_keys, &sk_nodes, &sk_n);
+                if (rc == DNAGPU_OK) {
+                    rc = run_tree(ctx, ps, nullptr, 0, n, k, sk_keys, 0, &tr, 0, 0, true, 0, ~0u, 0, sk_nodes, sk_n, 2);
+                    sorted = false;
+                    done = true;
+                } else if (rc != DNAGPU_SK_SKEWED) {
+                    done = true;
+                }
+            }
+            if (!done)
+                rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         }
         u64 *cursor = nullptr, *seg_off = nullptr;
         u32 *seg_cnt = nullptr;
@@ -1360,6 +1536,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             h->seg_off = seg_off;
             h->seg_cnt = seg_cnt;
             h->n_segs = tr.n_nodes;
+            h->sorted = sorted;
             ps.release(ok);
             ps.release(oc);
             ps.release(seg_off);
@@ -1386,6 +1563,20 @@ extern "C" int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
     return count_core(ctx, dna, first, count, k, nullptr, out);
     });
 }
+
+extern "C" int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
+                                            uint64_t count, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    HIP_TRY(hipSetDevice(ctx->device));
+    return count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, 0, 1, true);
+    });
+}
+
+extern "C" int dnagpu_hist_is_sorted(const dnagpu_hist *h) { return h && h->sorted ? 1 : 0; }
 
 extern "C" int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
                                         uint64_t count, int owner, int n_owners, dnagpu_hist **out)

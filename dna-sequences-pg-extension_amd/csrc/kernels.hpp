@@ -139,6 +139,23 @@ hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u3
                                 u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,
                                 u64 *dst_counts, hipStream_t s);
 
+// ---------------------------------------------------------------- superkmer_kernels.hip
+// super-k-mer (minimizer) partitioning for long k-mers: the dna sweeps (level 0: records per coarse digit of every
+// chunk of rows / records scattered into the coarse buckets), the record level (level 1: d1), and the expansion of
+// mid buckets into key nodes.  k in [sk_min_k(), 32]; c0n = coarse buckets, b1bits = bits of d1, r0bits = split
+// bits of the root (2^r0bits >= c0n); records are 16 bytes each.
+int sk_min_k();
+int sk_tile_rows();
+hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
+                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s);
+hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
+                           hipStream_t s);
+hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
+                              const u32 *tot, hipStream_t s);
+// mids[i] (start / len in records) -> keys at key_base[i] ..., out_nodes[16 i .. 16 i + 15]
+hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
+                            Node *out_nodes, hipStream_t s);
+
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();
 int scatter_threads();

@@ -130,4 +130,60 @@ __device__ __forceinline__ u32 wave_sum(u32 x)
     return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
 }
 
+// In-place exclusive scan of arr[0..n) in LDS by NT threads; returns the total.  The caller has
+// synchronised before the call; the function synchronises before returning.
+template <int NT>
+__device__ __forceinline__ u32 block_scan_inplace(u32 *arr, int n, u32 *wtmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n <= NT) {                          // one element per thread: no per-thread loops
+        const u32 v = tid < n ? arr[tid] : 0;
+        const u32 inc = wave_incl_scan(v);
+        if (lane == 63)
+            wtmp[wave] = inc;
+        __syncthreads();
+        // every wave scans the (at most 16) wave totals itself: one LDS read, one DPP scan
+        const u32 ws = wave_incl_scan(lane < NT / 64 ? wtmp[lane] : 0u);
+        const int wv1 = __builtin_amdgcn_readfirstlane(wave);
+        const u32 total1 = (u32)__builtin_amdgcn_readlane((int)ws, NT / 64 - 1);
+        const u32 wbase1 = wv1 ? (u32)__builtin_amdgcn_readlane((int)ws, wv1 - 1) : 0u;
+        if (tid < n)
+            arr[tid] = wbase1 + inc - v;
+        __syncthreads();
+        return total1;
+    }
+    const int per = (n + NT - 1) / NT;
+    const int b = tid * per;
+    const int e = (b + per < n) ? b + per : n;
+    u32 sum = 0;
+#pragma unroll 1
+    for (int i = b; i < e; i++)
+        sum += arr[i];
+    u32 inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(inc, off);
+        if (lane >= off)
+            inc += t;
+    }
+    if (lane == 63)
+        wtmp[wave] = inc;
+    __syncthreads();
+    // wave-uniform trip count: keeps the prefix in scalar code instead of NT/64 hoisted predicates
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    u32 wbase = 0, total = 0;
+    for (int w = 0; w < wv; w++)
+        wbase += wtmp[w];
+    for (int w = 0; w < NT / 64; w++)
+        total += wtmp[w];
+    u32 run = wbase + inc - sum;
+#pragma unroll 1
+    for (int i = b; i < e; i++) {
+        u32 v = arr[i];
+        arr[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
 }  // namespace dnagpu

@@ -171,6 +171,15 @@ typedef struct dnagpu_hist dnagpu_hist;
  * ascending key order through the segment directory.  At most 2^32-1 rows per call. */
 int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                        uint64_t first, uint64_t count, dnagpu_hist **out);
+/* The same groups when the caller does not need them in key order -- PostgreSQL's own GROUP BY order is
+ * unspecified (test.sql:95-104), so this is what the SQL entry point calls.  Long k-mers (k >= 23) of long
+ * sequences are then partitioned as super-k-mers (runs of consecutive k-mers sharing a minimizer, 16 bytes per
+ * ~9 k-mers) instead of 8-byte keys: less than a third of the partition traffic.  dnagpu_hist_download and
+ * dnagpu_hist_sorted_view then serve the groups bucket by bucket (keys ascending inside a bucket only);
+ * dnagpu_hist_is_sorted tells which kind a histogram is. */
+int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
+                                 uint64_t first, uint64_t count, dnagpu_hist **out);
+int dnagpu_hist_is_sorted(const dnagpu_hist *h);
 /* Same over an arbitrary array of n keys of k bases already in device memory.  dev_keys is used as
  * scratch and its contents are unspecified afterwards. */
 int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out);

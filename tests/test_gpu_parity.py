@@ -599,6 +599,63 @@ def test_count_keys_crafted_leaves(ctx, heavy, copies, light):
     d.free()
 
 
+# ------------------------------------------------------------------ GROUP BY without a promised order (super-k-mer engine)
+
+def check_hist_unordered(hist, ok, oc, what):
+    """same multiset of (key, count) groups as the oracle; order of the groups free (PostgreSQL's is unspecified)"""
+    gk, gc = hist.download()
+    assert hist.distinct == len(ok), f"{what}: {hist.distinct} groups, oracle {len(ok)}"
+    order = np.argsort(gk, kind="stable")
+    assert_same(gk[order], ok, what + " keys")
+    assert_same(gc[order], oc, what + " counts")
+    assert hist.summary() == orc.hist_summary(ok, oc), what + " summary"
+
+
+@pytest.mark.parametrize("n,k,first", [(5_000_011, 31, 0), (4_500_000, 32, 0), (6_000_000, 27, 7), (5_000_000, 23, 33),
+                                       (9_000_000, 31, 12345), (17_000_029, 31, 0), (40_000_000, 29, 1)])
+def test_count_unordered_superkmers(ctx, n, k, first):
+    """dnagpu_count_kmers_unordered on sequences long enough for super-k-mer partitioning: the groups are the
+    oracle's (sorted on the host for the comparison); a window that does not start on a word boundary"""
+    words = orc.synth_words(0x5EED + n, n)
+    d = ctx.upload(words, n)
+    keys = orc.generate_kmers(words, n, k, faithful=False)[first:]
+    ok, oc = orc.count_keys(keys)
+    h = ctx.count_kmers_unordered(d, k, first=first)
+    assert not h.is_sorted
+    assert h.total == len(keys)
+    check_hist_unordered(h, ok, oc, f"unordered n={n} k={k} first={first}")
+    h.free()
+    # short sequences and short k-mers take the ordinary engine behind the same entry point
+    h = ctx.count_kmers_unordered(d, 12, first=first, count=1_000_000)
+    assert h.is_sorted
+    ok, oc = orc.count_keys(orc.generate_kmers(words, n, 12, faithful=False)[first:first + 1_000_000])
+    check_hist(h, ok, oc, "unordered entry, short k")
+    h.free()
+    d.free()
+
+
+@pytest.mark.parametrize("kind", ["motif1000", "motif37", "polyA", "half-polyA", "AT"])
+def test_count_unordered_repeats(ctx, kind):
+    """repeat-rich and low-complexity inputs through the unordered entry: heavy buckets are split further by the
+    ordinary levels; a bucket too heavy for one workgroup sends the whole count to the ordinary engine"""
+    n, k = 6_000_000, 31
+    if kind.startswith("motif"):
+        words = orc.synth_words_repeat(91, n, int(kind[5:]))
+    elif kind == "polyA":
+        words = np.zeros((n + 31) // 32, dtype=np.uint64)
+    elif kind == "AT":
+        words, _ = orc.dna_encode("AT" * (n // 2))
+    else:
+        words = orc.synth_words(92, n)
+        words[: len(words) // 2] = 0
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_kmers(words, n, k)
+    h = ctx.count_kmers_unordered(d, k)
+    check_hist_unordered(h, ok, oc, f"unordered {kind}")
+    h.free()
+    d.free()
+
+
 # ------------------------------------------------------------------ batched operators
 
 def test_kmer_hash_batch(ctx, survey_vectors):
