@@ -1321,6 +1321,8 @@ __device__ __forceinline__ bool leaf_in_class(const Node &nd, int cls)
 {
     const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
     const int c = nd.len > (u32)LEAF_CAP_SMALL ? 2 : (nd.len > (u32)LEAF_CAP_TINY ? 1 : 0);
+    if (cls == 3)                                  // hashed leaves take both classes up to LEAF_CAP_SMALL
+        return sorts && c <= 1;
     return sorts && c == cls;                      // (single-key and empty nodes: emit_singles_kernel)
 }
 
@@ -1799,10 +1801,147 @@ __global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// hash_leaves: the leaves of a histogram whose groups need no order (dnagpu_count_kmers_unordered).  A leaf of at
+// most 4096 keys is counted in an LDS hash table of 8192 slots (linear probing, 64-bit compare-and-swap; counts
+// in 16-bit halves beside it) instead of being sorted: four barriers per leaf instead of ten, one LDS round trip
+// per key and probe instead of the sort's chain.  Groups leave in slot order: every wave compacts its eighth of
+// the table with ballots, so a store instruction writes one contiguous run.  The table is cleaned slot by slot
+// as it is emitted.  Same persistent structure as leaves_kernel: static leaf assignment through the class list,
+// the next leaf's keys requested while this one is emitted, output ranges from the cursor.
+constexpr int HL_NT = 512;
+constexpr int HL_ITEMS = LEAF_CAP_SMALL / HL_NT;      // 8 keys per thread
+constexpr int HL_SLOTS = 127 * 64;                   // 8128: with the 16-bit counts 79.4 KiB, two workgroups per CU
+constexpr u64 HL_EMPTY = ~(u64)0;                     // (the 32-base k-mer GG..G is counted beside the table)
+
+__global__ __launch_bounds__(HL_NT, 4) void hash_leaves_kernel(const Node *__restrict__ leaves, u32 n_leaves,
+                                                               const u64 *__restrict__ buf0, const u64 *__restrict__ buf1,
+                                                               unsigned long long *__restrict__ cursor,
+                                                               u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                               u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
+                                                               const u32 *__restrict__ list, u32 n_list)
+{
+    constexpr int WAVES = HL_NT / 64;
+    constexpr int CHUNKS = HL_SLOTS / 64;          // wave w emits the 64-slot chunks w, w + WAVES, ...
+    __shared__ __attribute__((aligned(16))) u64 tab[HL_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 cnt2[HL_SLOTS / 2];
+    unsigned short *cnt16 = reinterpret_cast<unsigned short *>(cnt2);
+    __shared__ u32 wtot[WAVES];
+    __shared__ u64 sh_obase;
+    __shared__ u32 ones_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 lq = blockIdx.x;
+    if (lq >= n_list)
+        return;
+    for (int q = tid; q < HL_SLOTS; q += HL_NT)
+        tab[q] = HL_EMPTY;
+    for (int q = tid; q < HL_SLOTS / 2; q += HL_NT)
+        cnt2[q] = 0;
+    if (tid == 0)
+        ones_cnt = 0;
+    u32 li = list[lq];
+    Node nd = leaves[li];
+    u64 key[HL_ITEMS];
+    {
+        const u64 *__restrict__ src = ((nd.meta & NODE_BUF) ? buf1 : buf0) + nd.start;
+#pragma unroll
+        for (int j = 0; j < HL_ITEMS; j++) {
+            const u32 i = tid + j * HL_NT;
+            key[j] = NT_LOAD(&src[i < nd.len ? i : nd.len - 1]);
+        }
+    }
+    for (;;) {
+        const u32 lq_next = lq + gridDim.x;
+        const bool has_next = lq_next < n_list;
+        const u32 ln = has_next ? list[lq_next] : li;
+        const Node nn = leaves[ln];
+        __syncthreads();                           // the table is clean, the previous leaf's emit is done
+        const u32 len = nd.len;
+#pragma unroll
+        for (int j = 0; j < HL_ITEMS; j++) {
+            const u32 i = tid + j * HL_NT;
+            if (i < len) {
+                const u64 kv = key[j];
+                if (kv == HL_EMPTY) {
+                    atomicAdd(&ones_cnt, 1u);
+                } else {
+                    u32 slot = (((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 16) * (u32)HL_SLOTS) >> 16;
+                    for (;;) {
+                        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
+                                                  (unsigned long long)HL_EMPTY, (unsigned long long)kv);
+                        if (old == HL_EMPTY || old == kv)
+                            break;
+                        slot = slot + 1 == (u32)HL_SLOTS ? 0u : slot + 1;
+                    }
+                    atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
+                }
+            }
+        }
+        // the next leaf's keys: in flight while this one is emitted
+        if (has_next) {
+            const u64 *__restrict__ src = ((nn.meta & NODE_BUF) ? buf1 : buf0) + nn.start;
+#pragma unroll
+            for (int j = 0; j < HL_ITEMS; j++) {
+                const u32 i = tid + j * HL_NT;
+                key[j] = NT_LOAD(&src[i < nn.len ? i : nn.len - 1]);
+            }
+        }
+        __syncthreads();
+        // occupied slots of this wave's part of the table
+        u32 mine = 0;
+        for (int ch = wave; ch < CHUNKS; ch += WAVES)
+            mine += (u32)__popcll(__ballot(cnt16[ch * 64 + lane] != 0));
+        if (lane == 0)
+            wtot[wave] = mine;
+        __syncthreads();
+        u32 before = 0, D = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            const u32 t = wtot[w];
+            before += w < wave ? t : 0u;
+            D += t;
+        }
+        const u32 ones = ones_cnt;
+        if (tid == 0) {
+            const u32 groups = D + (ones ? 1u : 0u);
+            const u64 ob = atomicAdd(cursor, (unsigned long long)groups);
+            sh_obase = ob;
+            seg_off[li] = ob;
+            seg_cnt[li] = groups;
+        }
+        __syncthreads();
+        const u64 obase = sh_obase;
+        u32 run = before;
+        for (int ch = wave; ch < CHUNKS; ch += WAVES) {
+            const u32 slot = (u32)(ch * 64 + lane);
+            const u32 c = cnt16[slot];
+            const u64 b = __ballot(c != 0);
+            if (c) {
+                const u32 r = run + (u32)__popcll(b & (((u64)1 << lane) - 1));
+                NT_STORE(tab[slot], &out_keys[obase + r]);
+                NT_STORE(c, &out_counts[obase + r]);
+                tab[slot] = HL_EMPTY;
+                cnt16[slot] = 0;
+            }
+            run += (u32)__popcll(b);
+        }
+        if (ones && tid == 0) {
+            out_keys[obase + D] = HL_EMPTY;
+            out_counts[obase + D] = ones;
+            ones_cnt = 0;
+        }
+        if (!has_next)
+            break;
+        lq = lq_next;
+        li = ln;
+        nd = nn;
+    }
+}
+
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0,
                          const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, u32 *list, hipStream_t s)
+                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed)
 {
     if (n_leaves == 0)
         return hipSuccess;
@@ -1854,6 +1993,20 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_sma
                                out_counts, dbg, (const u32 *)nullptr, 0u);                                            \
         LEAVES_STAMPS(#CAP_);                                                                                         \
     } while (0)
+    if (hashed && n_tiny + n_small > 0) {
+        // unordered histogram: every leaf of at most LEAF_CAP_SMALL keys is counted in an LDS hash table
+        const u32 g = (n_leaves + 255) / 256;
+        hipLaunchKernelGGL(class_flags_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, 3, flags);
+        hipError_t e3 = launch_scan_u32(flags, flags, n_leaves, scan_tmp, flags + n_leaves, s);
+        if (e3 != hipSuccess)
+            return e3;
+        hipLaunchKernelGGL(class_list_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, 3, flags, list);
+        hipLaunchKernelGGL(hash_leaves_kernel, dim3(leaves_grid(n_tiny + n_small, 2 * mult)), dim3(HL_NT), 0, s, leaves,
+                           n_leaves, buf0, buf1, cur, seg_off, seg_cnt, out_keys, out_counts, list, n_tiny + n_small);
+        LEAVES_STAMPS("hashed");
+        n_tiny = 0;
+        n_small = 0;
+    }
     if (n_tiny > 0)                                      // leaves of at most LEAF_CAP_TINY keys: 256-thread workgroups,
         LAUNCH_LEAVES(256, 8, LEAF_CAP_TINY, 8, mixed_tiny, 11);   // eight per CU, 2048 bins (what skew leaves behind)
     if (n_small > 0) {                                   // leaves of at most LEAF_CAP_SMALL keys

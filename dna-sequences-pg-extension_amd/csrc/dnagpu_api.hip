@@ -1231,12 +1231,12 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 }
 
 // ---- super-k-mer engine (superkmer_kernels.hip): the partition passes move 16-byte records of ~9 k-mers
-// instead of 8-byte keys.  On success *keys / *nodes / *n_nodes (pool memory of `ps`) are bucket nodes of about
-// SK_LEAF_MEAN keys over a key buffer: the ordinary tree continues from them at level 2.
-// DNAGPU_SK_SKEWED: a bucket is too heavy for the one workgroup that expands it (low-complexity input): the
-// caller counts with the ordinary tree instead, which has the skew paths.
+// instead of 8-byte keys, and a final bucket is counted from its records in an LDS hash table: no key of it is
+// ever written to HBM.
+// DNAGPU_SK_SKEWED: a bucket is too heavy (low-complexity input): the caller counts with the ordinary tree
+// instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
-constexpr u64 SK_LEAF_MEAN = 3800;               // planned keys per final node (LEAF_CAP 6144: > 7 sigma above)
+constexpr u64 SK_LEAF_MEAN = 3300;               // planned k-mers per final bucket: 4096 (the hash leaf's capacity) is > 3 sigma above
 constexpr u64 SK_MID_LIMIT = (u64)1 << 21;       // most k-mers one mid bucket may hold (planned: 16 x SK_LEAF_MEAN)
 
 struct SkLevel {                                 // what one forced partition level leaves behind
@@ -1271,24 +1271,23 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
     RC_TRY(ps.alloc((size_t)std::max<u32>(hc.n_chunks, 1) * ROW_STRIDE, &lv->tot));
     RC_TRY(ps.alloc(std::max<u32>(hc.n_next, 1), &lv->next));
     HIP_TRY(launch_fill_chunks(cur, n_nodes, chunk_len, outc, nch, cur, lv->chunks, st));
-    ps.free_now(scan_tmp);
-    // (outc / nch / ctr stay allocated until the scope ends: fill_chunks reads them asynchronously)
-    (void)hc;
+    // (outc / nch / scan_tmp / ctr go back to the pool when the scope ends: later users queue behind this stream)
     return DNAGPU_OK;
 }
 
-static int run_sk(dnagpu_ctx *ctx, PoolScope &ps_out, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 **keys,
-                  Node **nodes, u32 *n_nodes)
+// The three partition levels.  On success: *recs = the record buffer holding the final buckets, *fin / *n_fin =
+// their nodes (start / len in records, child_base = k-mers), all pool memory of `ps`.
+static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, void **recs,
+                        Node **fin, u32 *n_fin)
 {
     hipStream_t st = ctx->stream;
-    PoolScope ps(ctx);                           // everything but the keys and the final node list dies with this scope
-    // geometry: final nodes of ~SK_LEAF_MEAN keys = 16 per mid bucket; mid buckets = C0 coarse x 2^b1
+    // geometry: final buckets of ~SK_LEAF_MEAN k-mers = 16 per mid bucket; mid buckets = C0 coarse x 2^b1
     const u64 n_final = std::max<u64>(n / SK_LEAF_MEAN, 16);
     const u64 n_mid = (n_final + 15) / 16;
     int b1 = 1;
     while (b1 < MAX_SPLIT_BITS && ((u64)1 << b1) < n_mid)
         b1++;
-    const u32 c0n = (u32)std::min<u64>((n_mid + ((u64)1 << b1) - 1) >> b1, (u64)1 << MAX_SPLIT_BITS);
+    const u32 c0n = (u32)std::min<u64>((n_mid + ((u64)1 << b1) - 1) >> b1, (u64)sk_max_c0());
     int r0bits = 1;
     while ((1u << r0bits) < c0n)
         r0bits++;
@@ -1348,13 +1347,12 @@ static int run_sk(dnagpu_ctx *ctx, PoolScope &ps_out, const dnagpu_dna *dna, u64
     prof_mark(ctx, "sk_scatter1");
     HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
 
-    // ---- k-mers per mid bucket -> key ranges (host: the list is short), skew check
-    std::vector<u32> kc(l1.n_next), kb(l1.n_next);
+    // ---- skew check on the k-mers per mid bucket (the list is short: host)
+    std::vector<u32> kc(l1.n_next);
     HIP_TRY(hipMemcpyAsync(kc.data(), kcount, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     u64 run = 0, heaviest = 0;
     for (u32 i = 0; i < l1.n_next; i++) {
-        kb[i] = (u32)run;
         run += kc[i];
         heaviest = std::max<u64>(heaviest, kc[i]);
     }
@@ -1364,19 +1362,110 @@ static int run_sk(dnagpu_ctx *ctx, PoolScope &ps_out, const dnagpu_dna *dna, u64
     }
     if (heaviest > SK_MID_LIMIT)
         return DNAGPU_SK_SKEWED;
-    u32 *key_base = nullptr;
-    RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &key_base));
-    HIP_TRY(hipMemcpyAsync(key_base, kb.data(), (size_t)l1.n_next * sizeof(u32), hipMemcpyHostToDevice, st));
-    u64 *kbuf = nullptr;
+
+    // ---- level 2: every mid bucket regrouped by d2 (rec1 -> rec0): 16 final buckets each
+    Node *fn = nullptr;
+    RC_TRY(ps.alloc((size_t)l1.n_next * 16, &fn));
+    prof_mark(ctx, "sk_regroup");
+    HIP_TRY(launch_sk_regroup(l1.next, l1.n_next, rec1, rec0, fn, st));
+    ps.free_now(rec1);
+    *recs = rec0;
+    *fin = fn;
+    *n_fin = l1.n_next * 16;
+    return DNAGPU_OK;
+}
+
+// The whole count: partition, then final buckets of at most sk_count_cap() k-mers are counted from their records
+// (sk_count), the others expanded to keys and counted by the ordinary levels.  Fills h on success.
+static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, dnagpu_hist *h)
+{
+    hipStream_t st = ctx->stream;
+    PoolScope ps(ctx);
+    void *recs = nullptr;
     Node *fin = nullptr;
-    RC_TRY(ps_out.alloc((size_t)n, &kbuf));
-    RC_TRY(ps_out.alloc((size_t)l1.n_next * 16, &fin));
-    prof_mark(ctx, "sk_expand");
-    HIP_TRY(launch_sk_expand(l1.next, l1.n_next, rec1, key_base, k, kbuf, fin, st));
-    HIP_TRY(hipStreamSynchronize(st));           // kb / kc are host vectors
-    *keys = kbuf;
-    *nodes = fin;
-    *n_nodes = l1.n_next * 16;
+    u32 n_fin = 0;
+    RC_TRY(sk_partition(ctx, ps, dna, first, n, k, &recs, &fin, &n_fin));
+    prof_mark(ctx, "sk_select");
+    const u32 cap = (u32)sk_count_cap();
+    u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *scan_tmp = nullptr, *totals = nullptr, *list_small = nullptr;
+    RC_TRY(ps.alloc((size_t)n_fin, &f_small));
+    RC_TRY(ps.alloc((size_t)n_fin, &f_over));
+    RC_TRY(ps.alloc((size_t)n_fin, &k_over));
+    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_fin), &scan_tmp));
+    RC_TRY(ps.alloc(4, &totals));
+    RC_TRY(ps.alloc((size_t)n_fin, &list_small));
+    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, f_small, f_over, k_over, st));
+    HIP_TRY(launch_scan_u32(f_small, f_small, n_fin, scan_tmp, totals + 0, st));
+    HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 1, st));
+    HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 2, st));
+    u32 ht[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(ht, totals, sizeof ht, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const u32 n_small = ht[0], n_over = ht[1];
+    const u64 over_keys = ht[2];
+    Node *over_nodes = nullptr;
+    u32 *over_kbase = nullptr;
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_nodes));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_kbase));
+    HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, f_small, f_over, k_over, list_small, over_nodes, over_kbase, st));
+
+    // output arrays and the segment directory: final buckets first, the nodes of the oversize buckets' tree behind them
+    u64 *cursor = nullptr, *ok = nullptr;
+    u32 *oc = nullptr;
+    RC_TRY(ps.alloc(1, &cursor));
+    RC_TRY(ps.alloc((size_t)n, &ok));
+    RC_TRY(ps.alloc((size_t)n, &oc));
+    HIP_TRY(hipMemsetAsync(cursor, 0, 8, st));
+    TreeResult tr;
+    memset(&tr, 0, sizeof tr);
+    u64 *seg_off = nullptr;
+    u32 *seg_cnt = nullptr;
+    if (n_over > 0) {
+        // oversize buckets (heavy repeats, or the tail of the size distribution): keys, then the ordinary levels
+        u64 *kbuf = nullptr;
+        Node *knodes = nullptr;
+        RC_TRY(ps.alloc((size_t)over_keys, &kbuf));
+        RC_TRY(ps.alloc((size_t)n_over * 16, &knodes));
+        prof_mark(ctx, "sk_expand");
+        HIP_TRY(launch_sk_expand(over_nodes, n_over, recs, over_kbase, k, kbuf, knodes, st));
+        RC_TRY(run_tree(ctx, ps, nullptr, 0, over_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes, n_over * 16, 2));
+    }
+    const u32 n_segs = n_fin + tr.n_nodes;
+    RC_TRY(ps.alloc((size_t)n_segs, &seg_off));
+    RC_TRY(ps.alloc((size_t)n_segs, &seg_cnt));
+    HIP_TRY(hipMemsetAsync(seg_cnt, 0, (size_t)n_fin * sizeof(u32), st));     // empty and oversize buckets: no groups of their own
+    HIP_TRY(hipMemsetAsync(seg_off, 0, (size_t)n_fin * sizeof(u64), st));
+    if (tr.n_nodes > 0) {
+        u32 *flags = nullptr, *ltmp = nullptr, *cls_list = nullptr;
+        RC_TRY(ps.alloc((size_t)tr.n_nodes + 1, &flags));
+        RC_TRY(ps.alloc((size_t)scan_tmp_words(tr.n_nodes), &ltmp));
+        RC_TRY(ps.alloc((size_t)tr.n_nodes, &cls_list));
+        prof_mark(ctx, "leaves");
+        HIP_TRY(launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off + n_fin,
+                              seg_cnt + n_fin, ok, oc, flags, ltmp, cls_list, st, true));
+    }
+    prof_mark(ctx, "sk_count");
+    HIP_TRY(launch_sk_count(fin, list_small, n_small, recs, k, cursor, seg_off, seg_cnt, ok, oc, st));
+    prof_mark(ctx, "end");
+    u64 total_groups = 0;
+    HIP_TRY(hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total_groups > n) {
+        set_err("super-k-mer count: %llu groups for %llu rows", (unsigned long long)total_groups, (unsigned long long)n);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    h->total = n;
+    h->n_distinct = total_groups;
+    h->keys = ok;
+    h->counts = oc;
+    h->seg_off = seg_off;
+    h->seg_cnt = seg_cnt;
+    h->n_segs = n_segs;
+    h->sorted = false;
+    ps.release(ok);
+    ps.release(oc);
+    ps.release(seg_off);
+    ps.release(seg_cnt);
     return DNAGPU_OK;
 }
 
@@ -1399,6 +1488,19 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     prof_begin(ctx);
     int rc;
     bool sorted = true;                          // segments in ascending key order (false: bucket order of the super-k-mer engine)
+    if (any_order && dna && fixed_bits == 0 && n_owners == 1 && k >= sk_min_k() && n >= SK_MIN_ROWS) {
+        rc = count_sk(ctx, dna, first, n, k, h);
+        if (rc != DNAGPU_SK_SKEWED) {
+            prof_end(ctx);
+            if (rc != DNAGPU_OK) {
+                delete h;
+                return rc;
+            }
+            *out = h;
+            return DNAGPU_OK;
+        }
+        prof_begin(ctx);                         // a bucket too heavy for the engine: the ordinary tree from scratch
+    }
     if (dna && n_owners == 1 && fixed_bits == 0 && 2 * k <= dense_max_bits() && n > (u64)LEAF_CAP &&
         n >= ((u64)(2 * k > 16 ? 64 : 4) << (2 * k))) {   // (enough rows to pay for the passes and for compacting the table)
         // short k-mers: the histogram is a table of at most 262,144 counters filled straight from the
@@ -1469,20 +1571,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             }
             rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo, span, tb);
         } else {
-            bool done = false;
-            if (any_order && dna && fixed_bits == 0 && k >= sk_min_k() && n >= SK_MIN_ROWS) {
-                u64 *sk_keys = nullptr;
-                Node *sk_nodes = nullptr;
-                u32 sk_n = 0;
-                rc = run_sk(ctx, ps, dna, first, n, k, &sk_keys, &sk_nodes, &sk_n);
-                if (rc == DNAGPU_OK) {
-                    rc = run_tree(ctx, ps, nullptr, 0, n, k, sk_keys, 0, &tr, 0, 0, true, 0, ~0u, 0, sk_nodes, sk_n, 2);
-                    sorted = false;
-                    done = true;
-                } else if (rc != DNAGPU_SK_SKEWED) {
-                    done = true;
-                }
-            }
+            const bool done = false;
             if (!done)
                 rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         }
@@ -1500,7 +1589,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
         u32 *flags = nullptr, *scan_tmp = nullptr, *cls_list = nullptr;
-        if (rc == DNAGPU_OK && tr.n_tiny != tr.n_nodes && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes) {
+        if (rc == DNAGPU_OK && (!sorted || (tr.n_tiny != tr.n_nodes && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes))) {
             // a mixed node list: single-key / empty nodes are emitted in bulk, each leaf class gets an index list
             rc = ps.alloc((size_t)tr.n_nodes + 1, &flags);
             if (rc == DNAGPU_OK) rc = ps.alloc((size_t)scan_tmp_words(tr.n_nodes), &scan_tmp);
@@ -1513,7 +1602,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
                 e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt,
-                                  ok, oc, flags, scan_tmp, cls_list, ctx->stream);
+                                  ok, oc, flags, scan_tmp, cls_list, ctx->stream, !sorted);
             prof_mark(ctx, "end");
             if (e == hipSuccess)
                 e = hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);

@@ -123,12 +123,14 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
                                 hipStream_t s);
 // leaves -> (key, count) groups appended densely to out_keys/out_counts at offsets taken from *cursor
 // (zeroed; holds the group count afterwards); seg_off/seg_cnt[l] = where leaf l landed.
+// hashed: the groups of a leaf need no order -- leaves of at most LEAF_CAP_SMALL keys are counted in an LDS hash table
+// (flags / scan_tmp / list are then always needed).
 // n_tiny / n_small / n_big: leaves per sorting class; the other leaves hold one distinct key (or none) and are emitted
 // in bulk; flags / scan_tmp / list (n_leaves + 1, scan_tmp_words(n_leaves) and n_leaves u32) are needed unless all
 // nodes are sorting leaves of one class
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, u32 *list, hipStream_t s);
+                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed = false);
 // dense count of short k-mers straight from the packed sequence (2k = bits <= dense_max_bits()): table must hold
 // 2^bits u32 counters, out_keys/out_counts 2^bits entries; *n_out = distinct keys; results ascending
 int dense_max_bits();
@@ -146,6 +148,7 @@ hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u3
 // bits of the root (2^r0bits >= c0n); records are 16 bytes each.
 int sk_min_k();
 int sk_tile_rows();
+int sk_max_c0();          // most coarse buckets the level-0 sweeps support
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
                             u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s);
 hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
@@ -155,6 +158,19 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
 // mids[i] (start / len in records) -> keys at key_base[i] ..., out_nodes[16 i .. 16 i + 15]
 hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
                             Node *out_nodes, hipStream_t s);
+
+// every mid bucket's records regrouped by d2 from src into the same range of dst; out_nodes[16 i + j] = final bucket:
+// start / len in records, child_base = its k-mers
+hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s);
+// final buckets list[0..n_list) (indices into fin) counted from their records in an LDS hash table; groups appended
+// at *cursor, seg_off / seg_cnt[bucket] = where they went
+hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const void *recs, int k, u64 *cursor, u64 *seg_off,
+                           u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
+
+int sk_count_cap();       // most k-mers a final bucket may hold to be counted from its records
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, hipStream_t s);
+hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
+                                  u32 *list_small, Node *over_nodes, u32 *over_kbase, hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();

@@ -20,15 +20,21 @@
 // the result.  Group order: nodes in bucket order, ascending inside a node -- NOT globally ascending, which
 // is why this engine sits behind dnagpu_count_kmers_unordered (PostgreSQL's GROUP BY order is unspecified,
 // test.sql:95-104).
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace dnagpu {
 
 constexpr int SK_NT = 256;                       // threads of a front-end workgroup
 constexpr int SK_TILE_ROWS = (SK_NT - 1) * 32;   // rows (k-mers) a tile emits records for: the last thread only supplies hashes
-constexpr int SK_STAGE = 2048;                   // descriptors staged per scatter round
+constexpr int SK_MAX_C0 = 128;                   // most coarse buckets (digits of level 0): 2^32 rows need 80
+constexpr int SK_LIST = 2048;                    // records of a tile listed in LDS (a tile of random bases has ~900)
 
 int sk_tile_rows() { return SK_TILE_ROWS; }
+int sk_max_c0() { return SK_MAX_C0; }
+int sk_count_cap() { return 4096; }              // distinct keys of a bucket <= its k-mers <= half the 8128-slot table
 
 typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
 
@@ -87,7 +93,8 @@ struct SkFront {
 
 template <int W>
 __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 n_rows,
-                                         u32 lmax, u32 *hs /* [(W-1) * SK_NT] */, u32 *hx /* [2 * SK_NT + 8] */)
+                                         u32 lmax, u32 *hs /* [(W-1) * SK_NT] */, u32 *hx /* [2 * SK_NT + 8] */,
+                                         u64 *wsh /* [SK_NT + 2] or null: the tile's words, word 0 = the one holding pos0 */)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the 64 bases from this thread's first row on (pos0 + 32 t): 4 dwords
@@ -96,10 +103,20 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     const unsigned sh = (unsigned)(pos & 31) * 2;          // workgroup-uniform
     const u64 w0 = w < n_words ? words[w] : 0, w1 = w + 1 < n_words ? words[w + 1] : 0;
     u64 lo = w0, hi = w1;
-    if (sh) {
-        const u64 w2 = w + 2 < n_words ? words[w + 2] : 0;
-        lo = (w0 >> sh) | (w1 << (64 - sh));
-        hi = (w1 >> sh) | (w2 << (64 - sh));
+    u64 w2 = 0;
+    if (sh || (wsh && tid == SK_NT - 1)) {
+        w2 = w + 2 < n_words ? words[w + 2] : 0;
+        if (sh) {
+            lo = (w0 >> sh) | (w1 << (64 - sh));
+            hi = (w1 >> sh) | (w2 << (64 - sh));
+        }
+    }
+    if (wsh) {                                             // (the previous tile's readers are behind this tile's barriers... see below)
+        wsh[tid] = w0;
+        if (tid == SK_NT - 1) {
+            wsh[SK_NT] = w1;
+            wsh[SK_NT + 1] = w2;
+        }
     }
     const u32 d[4] = {(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
     u32 a[32 + W - 1];
@@ -164,7 +181,29 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     __syncthreads();                                       // hs / hx may be rewritten by the caller
 }
 
-// walks the thread's rows in order and calls emit(end_row, len, hmin) for every record that ENDS in them
+// the same walk with the callback at EVERY row position (end = a record ends at this thread's row j; false for rows
+// that do not exist), so that the callback may use wave-wide operations
+template <int W, typename Emit>
+__device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Emit &&emit)
+{
+    const u32 r0 = (u32)threadIdx.x * 32;
+    u32 c = f.c0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        bool end = false;
+        if ((u32)j < f.n_valid) {
+            if (j > 0 && f.hm[j] != f.hm[j - 1])
+                c = 0;
+            const u32 nxt = j < 31 ? f.hm[j + 1] : f.next_first;
+            end = r0 + (u32)j + 1 == f.n_rows || nxt != f.hm[j] || c + 1 == lmax;
+        }
+        emit(j, end, r0 + (u32)j, c + 1, f.hm[j]);
+        c = end ? 0u : c + 1;
+    }
+}
+
+// walks the thread's rows in order and calls emit(j, end_row, len, hmin) for every record that ENDS in them (j = the
+// row's index among the thread's 32: a constant once the loop is unrolled)
 template <int W, typename Emit>
 __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
@@ -179,7 +218,7 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &
             const bool last = r0 + (u32)j + 1 == f.n_rows;   // records are cut at the tile's end
             const bool end = last || nxt != f.hm[j] || c + 1 == lmax;
             if (end) {
-                emit(r0 + (u32)j, c + 1, f.hm[j]);
+                emit(j, r0 + (u32)j, c + 1, f.hm[j]);
                 c = 0;
             } else {
                 c++;
@@ -198,7 +237,7 @@ __global__ __launch_bounds__(SK_NT) void sk_hist0_kernel(const Chunk *__restrict
 {
     __shared__ u32 hs[(W - 1) * SK_NT];
     __shared__ u32 hx[2 * SK_NT + 8];
-    __shared__ u32 h[ROW_STRIDE];
+    __shared__ u32 h[SK_MAX_C0];
     if (blockIdx.x >= n_chunks)
         return;
     const Chunk ch = chunks[blockIdx.x];
@@ -208,9 +247,9 @@ __global__ __launch_bounds__(SK_NT) void sk_hist0_kernel(const Chunk *__restrict
     for (u32 t0 = 0; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SK_TILE_ROWS ? ch.len - t0 : (u32)SK_TILE_ROWS;
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, hs, hx);
+        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, hs, hx, nullptr);
         if (threadIdx.x < SK_NT - 1)
-            sk_records<W>(f, lmax, [&](u32, u32, u32 hmin) { atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u); });
+            sk_records<W>(f, lmax, [&](int, u32, u32, u32 hmin) { atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u); });
     }
     __syncthreads();
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;
@@ -219,25 +258,23 @@ __global__ __launch_bounds__(SK_NT) void sk_hist0_kernel(const Chunk *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// sk_scatter0: the same sweep; the records of a tile are staged digit-sorted in LDS (as descriptors) and written
-// out run by run: 16 bytes per lane, a digit's records consecutive.
-//   descriptor = hmin << 32 | start row in tile << 5 | (len - 1)
-//   record     = lo: bases 0..31 of the run; hi: bases 32..53 (bits 0..43) | (len-1) << 44 | d1 << 49 | d2 << 59
+// sk_scatter0: the same sweep; every record goes straight to its coarse bucket.  The chunk owns a range of
+// every bucket (histogram prefix), so a per-digit cursor in LDS hands out consecutive slots; with at most a few
+// dozen coarse digits the open cache lines of a workgroup are few and the 16-byte stores combine in L2.
+//   record = lo: bases 0..31 of the run; hi: bases 32..53 (bits 0..43) | (len-1) << 44 | d1 << 49 | d2 << 59
 template <int W>
-__global__ __launch_bounds__(SK_NT) void sk_scatter0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
+__global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                             const u64 *__restrict__ words, u64 n_words, u64 first, int k,
                                                             u32 lmax, u32 c0n, u32 b1mask, u32 r0n,
                                                             const u32 *__restrict__ hist, const u32 *__restrict__ tot,
-                                                            ull2_t *__restrict__ recs)
+                                                            ull2_t *__restrict__ recs, int dbg)
 {
     __shared__ u32 hs[(W - 1) * SK_NT];
     __shared__ u32 hx[2 * SK_NT + 8];
-    __shared__ u32 cnt[ROW_STRIDE];               // records per digit of this round -> exclusive offsets in the stage
-    __shared__ u32 cur[ROW_STRIDE];               // placement cursors
-    __shared__ u32 gpos[ROW_STRIDE];              // where the chunk's next record of each digit goes
-    __shared__ u64 stage[SK_STAGE];
-    __shared__ u32 wtmp[SK_NT / 64];
-    __shared__ u32 round_total;
+    __shared__ u32 gpos[SK_MAX_C0];               // where the chunk's next record of each digit goes
+    __shared__ u64 wsh[SK_NT + 2];                // the tile's packed words: record payloads are cut from here
+    __shared__ u64 list[SK_LIST];                 // hmin << 32 | start row << 5 | (len-1)
+    __shared__ u32 wtot[SK_NT / 64];
     if (blockIdx.x >= n_chunks)
         return;
     const int tid = threadIdx.x;
@@ -250,70 +287,86 @@ __global__ __launch_bounds__(SK_NT) void sk_scatter0_kernel(const Chunk *__restr
     for (u32 t0 = 0; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SK_TILE_ROWS ? ch.len - t0 : (u32)SK_TILE_ROWS;
         const u64 tile_pos = first + ch.off + t0;
+        const u32 fo = (u32)(tile_pos & 31);
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, hs, hx);
-        // a tile holds at most 8160 records, usually ~900: one round when they fit the stage, else one round per wave
-        // (a wave's 64 threads end at most 2048 records)
-        u32 mine = 0;
-        if (tid < SK_NT - 1)
-            sk_records<W>(f, lmax, [&](u32, u32, u32) { mine++; });
-        const u32 tot_recs = wave_sum(mine);
-        if ((tid & 63) == 0)
-            wtmp[tid >> 6] = tot_recs;
-        __syncthreads();
-        u32 all = 0;
-        for (int q = 0; q < SK_NT / 64; q++)
-            all += wtmp[q];
-        const int n_rounds = all <= (u32)SK_STAGE ? 1 : SK_NT / 64;
-        for (int round = 0; round < n_rounds; round++) {
-            const bool in_round = tid < SK_NT - 1 && (n_rounds == 1 || (tid >> 6) == round);
-            for (u32 d = tid; d < r0n; d += SK_NT)
-                cnt[d] = 0;
-            __syncthreads();
-            if (in_round)
-                sk_records<W>(f, lmax, [&](u32, u32, u32 hmin) { atomicAdd(&cnt[sk_digits(hmin, c0n, b1mask).d0], 1u); });
-            __syncthreads();
-            const u32 n_stage = block_scan_inplace<SK_NT>(cnt, (int)r0n, wtmp);   // cnt -> exclusive offsets
-            for (u32 d = tid; d < r0n; d += SK_NT)
-                cur[d] = cnt[d];
-            if (tid == 0)
-                round_total = n_stage;
-            __syncthreads();
-            if (in_round)
-                sk_records<W>(f, lmax, [&](u32 end_row, u32 len, u32 hmin) {
-                    const u32 slot = atomicAdd(&cur[sk_digits(hmin, c0n, b1mask).d0], 1u);
-                    stage[slot] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 5) | (u64)(len - 1);
+        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, hs, hx, wsh);
+        // The records that end in this tile (usually ~900) are listed in LDS, every wave in its own quarter of the list
+        // (ballot + prefix count per row position: no atomics), and every thread then builds the payloads of its share
+        // -- building them where they end would run the payload code for all 32 row positions of every wave, ~9 times
+        // the work.  A wave that would overflow its quarter (a tile of very short runs: low-complexity sequence) has the
+        // tile redone in four passes of eight row positions each, which always fit.
+        constexpr u32 WCAP = SK_LIST / (SK_NT / 64);
+        int n_pass = 1;
+        for (int pass = 0; pass < n_pass; pass++) {
+            const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
+            u32 wrun = 0;                          // wave-uniform: records this wave has listed
+            {
+                u64 *wl = list + (u32)(tid >> 6) * WCAP;
+                const u64 below = ((u64)1 << (tid & 63)) - 1;
+                sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
+                    const bool end = end_any && j >= jlo && j < jhi;
+                    const u64 b = __ballot(end);
+                    if (end) {
+                        const u32 pos = wrun + (u32)__popcll(b & below);
+                        if (pos < WCAP)
+                            wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 5) | (u64)(len - 1);
+                    }
+                    wrun += (u32)__popcll(b);
                 });
-            __syncthreads();
-            // write out: slot i -> recs[gpos[d0] + (i - cnt[d0])]
-            for (u32 i = tid; i < round_total; i += SK_NT) {
-                const u64 desc = stage[i];
-                const u32 hmin = (u32)(desc >> 32), len = (u32)(desc & 31) + 1, start = (u32)(desc >> 5) & 0x3FFFu;
-                const SkDigits dg = sk_digits(hmin, c0n, b1mask);
-                const u64 p = tile_pos + start;                     // stream position of the run's first base
-                const u64 wi = p >> 5;
-                const unsigned s = (unsigned)(p & 31) * 2;
-                const u64 a0 = wi < n_words ? words[wi] : 0, a1 = wi + 1 < n_words ? words[wi + 1] : 0,
-                          a2 = wi + 2 < n_words ? words[wi + 2] : 0;
-                u64 lo = funnel(a0, a1, s), hi = funnel(a1, a2, s);
-                const u32 nb = len + (u32)k - 1;                    // bases of the run: <= 54
-                if (nb < 32) {
-                    lo &= ((u64)1 << (2 * nb)) - 1;
-                    hi = 0;
-                } else {
-                    hi &= ((u64)1 << (2 * (nb - 32))) - 1;         // nb - 32 <= 22
-                }
-                hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59);
-                ull2_t r;
-                r.x = lo;
-                r.y = hi;
-                recs[gpos[dg.d0] + (i - cnt[dg.d0])] = r;
             }
+            if ((tid & 63) == 0)
+                wtot[tid >> 6] = wrun;
             __syncthreads();
-            // advance the chunk's cursors by this round's counts: cur[d] ended at cnt[d] + count[d]
-            for (u32 d = tid; d < r0n; d += SK_NT)
-                gpos[d] += cur[d] - cnt[d];
-            __syncthreads();
+            u32 tile_recs = 0, wmax = 0;
+            u32 wbase[SK_NT / 64 + 1];
+#pragma unroll
+            for (int q = 0; q < SK_NT / 64; q++) {
+                wbase[q] = tile_recs;
+                tile_recs += wtot[q];
+                wmax = max(wmax, wtot[q]);
+            }
+            wbase[SK_NT / 64] = tile_recs;
+            if (wmax > WCAP) {                     // (only possible in the single pass: eight rows x 64 lanes = WCAP)
+                n_pass = 4;
+                pass = -1;
+                __syncthreads();
+                continue;
+            }
+            if (!(dbg & 2))
+                for (u32 e = tid; e < tile_recs; e += SK_NT) {
+                    u32 wq = 0;
+#pragma unroll
+                    for (int q = 1; q < SK_NT / 64; q++)
+                        wq += e >= wbase[q] ? 1u : 0u;
+                    u32 eb = 0;
+#pragma unroll
+                    for (int q = 1; q < SK_NT / 64; q++)
+                        eb = wq == (u32)q ? wbase[q] : eb;
+                    const u64 en = list[wq * WCAP + (e - eb)];
+                    const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
+                    const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
+                    const u32 len = ((u32)en & 31u) + 1u;
+                    const u32 q = ((u32)(en >> 5) & 0x1FFFu) + fo; // first base of the run, relative to the tile's first word
+                    const u32 wi = q >> 5, sh = (q & 31u) * 2u;
+                    const u64 a0 = wsh[wi], a1 = wsh[wi + 1], a2 = wsh[wi + 2];
+                    u64 lo = funnel(a0, a1, sh), hi = funnel(a1, a2, sh);
+                    const u32 nb = len + (u32)k - 1;
+                    if (nb < 32) {
+                        lo &= ((u64)1 << (2 * nb)) - 1;
+                        hi = 0;
+                    } else {
+                        hi &= ((u64)1 << (2 * (nb - 32))) - 1;
+                    }
+                    hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59);
+                    ull2_t r;
+                    r.x = lo;
+                    r.y = hi;
+                    if (!(dbg & 1))
+                        recs[gslot] = r;
+                    else if (r.x == 0x1234567 && r.y == 0x89)
+                        recs[0] = r;
+                }
+            __syncthreads();                       // wsh / list are rewritten by the next pass / tile
         }
     }
 }
@@ -357,7 +410,7 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
 // to their mid buckets 16 bytes per lane (8 records per digit and tile on average: 128-byte runs)
 constexpr int SK1_ITEMS = 8;
 constexpr int SK1_TILE = SK1_NT * SK1_ITEMS;
-__global__ __launch_bounds__(SK1_NT) void sk_scatter1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
+__global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
                                                              u32 n_chunks, const ull2_t *__restrict__ src_all,
                                                              ull2_t *__restrict__ dst_all, const u32 *__restrict__ hist,
                                                              const u32 *__restrict__ tot)
@@ -423,125 +476,588 @@ __global__ __launch_bounds__(SK1_NT) void sk_scatter1_kernel(const Node *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// sk_expand: one workgroup per mid bucket.  Sweep A counts the bucket's k-mers per d2; the bucket's key range
-// (key_base[node], from the scan of kcount) is cut into 16 nodes accordingly.  Sweep B takes 256 records at a
-// time, stages their keys grouped by d2 in LDS and copies every group to its node's range, coalesced.
-constexpr int SKX_NT = 256;
-constexpr int SKX_STAGE = SKX_NT * 32;            // keys of 256 records of at most 32 k-mers
+// sk_expand: one WAVE per mid bucket, no workgroup barrier anywhere.  Sweep A counts the bucket's k-mers per d2;
+// the bucket's key range (key_base[bucket], from the scan of kcount) is cut into 16 nodes accordingly.  Sweep B
+// takes 64 records at a time (the next 64 already requested), stages their keys grouped by d2 in the wave's
+// LDS slice and copies every group to its node's range, coalesced.
+constexpr int SKX_WAVES = 4;
+constexpr int SKX_NT = 64 * SKX_WAVES;
+
+// LDS written by one lane and read by another of the same wave: DS operations of a wave execute in program
+// order, so only the compiler has to be kept from reordering them
+__device__ __forceinline__ void sk_wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exclusive scan over lanes 0..15 (one DPP row); lanes >= 16 get garbage
+__device__ __forceinline__ u32 row16_excl_scan(u32 x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    return (u32)v - x;
+}
+
 __global__ __launch_bounds__(SKX_NT) void sk_expand_kernel(const Node *__restrict__ mids, u32 n_mids,
                                                            const ull2_t *__restrict__ recs,
-                                                           const u32 *__restrict__ key_base, int k,
-                                                           u64 *__restrict__ keys, Node *__restrict__ out_nodes)
+                                                           const u32 *__restrict__ key_base, int k, u32 lmax,
+                                                           u64 *__restrict__ keys, Node *__restrict__ out_nodes, int dbg)
 {
-    __shared__ u32 kc[64][17];                    // sweep A: per-lane copies of the 16 k-mer counters
-    __shared__ u32 nbase[17];                     // node j's keys start at key_base + nbase[j]
-    __shared__ u32 done[16];                      // keys of node j already written
-    __shared__ u32 sc[16], sb[17];                // this batch: keys per d2, their offsets in the stage
-    __shared__ u32 scur[16];
-    __shared__ u64 stage[SKX_STAGE];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 i = blockIdx.x * SKX_WAVES + (u32)wave;
+    if (i >= n_mids)
+        return;                                   // (whole waves leave: nothing below synchronises across waves)
+    const u32 stage_keys = 64u * lmax;
+    unsigned char *mine = sk_smem + (size_t)wave * ((size_t)stage_keys * 8 + 5 * 16 * 4);
+    u64 *stage = reinterpret_cast<u64 *>(mine);
+    u32 *sc = reinterpret_cast<u32 *>(mine + (size_t)stage_keys * 8);   // keys per d2 (sweep A: of the bucket; B: of the batch)
+    u32 *scur = sc + 16, *nbase = sc + 32, *done = sc + 48;
+    const Node nd = mids[i];
+    const u64 kmask = kmer_mask(k);
+    const ull2_t *src = recs + (u64)nd.start;
+
+    if (lane < 16) {
+        sc[lane] = 0;
+        done[lane] = 0;
+    }
+    sk_wave_fence();
+    // (eight independent loads per lane in flight: one wave per bucket has little else to hide their latency)
+    for (u32 r0 = 0; r0 < nd.len; r0 += 64 * 8) {
+        u64 m[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const u32 r = r0 + (u32)q * 64 + (u32)lane;
+            m[q] = r < nd.len ? __builtin_nontemporal_load(&reinterpret_cast<const u64 *>(src + r)[1]) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (r0 + (u32)q * 64 + (u32)lane < nd.len)
+                atomicAdd(&sc[(u32)(m[q] >> 59) & 15u], (u32)((m[q] >> 44) & 31) + 1u);
+    }
+    sk_wave_fence();
+    const u32 kb = key_base[i];
+    {
+        const u32 v = lane < 16 ? sc[lane] : 0u;
+        const u32 ex = row16_excl_scan(v);
+        if (lane < 16) {
+            nbase[lane] = ex;
+            Node o;
+            o.start = kb + ex;
+            o.len = v;
+            o.meta = (u32)(2 * k);                // no key bit is fixed: the leaves sort on the top bits; buffer 0
+            o.split = 0;
+            o.prefix = 0;
+            o.child_base = 0;
+            o.chunk_base = 0;
+            out_nodes[(u64)i * 16 + lane] = o;
+        }
+    }
+    // the records of the next SKX_AHEAD batches are always in flight
+    constexpr int SKX_AHEAD = 4;
+    ull2_t ring[SKX_AHEAD];
+#pragma unroll
+    for (int q = 0; q < SKX_AHEAD; q++) {
+        ring[q].x = 0;
+        ring[q].y = 0;
+        if ((u32)q * 64 + (u32)lane < nd.len)
+            ring[q] = src[q * 64 + lane];
+    }
+    for (u32 g0 = 0; g0 < nd.len; g0 += 64 * SKX_AHEAD)
+#pragma unroll
+    for (int gq = 0; gq < SKX_AHEAD; gq++) {
+        const u32 b0 = g0 + (u32)gq * 64;
+        if (b0 >= nd.len)                                  // wave-uniform
+            break;
+        const ull2_t rec = ring[gq];
+        const bool have = b0 + (u32)lane < nd.len;
+        if (b0 + 64 * SKX_AHEAD + (u32)lane < nd.len)
+            ring[gq] = src[b0 + 64 * SKX_AHEAD + lane];
+        const u32 len = have ? (u32)((rec.y >> 44) & 31) + 1u : 0u;
+        const u32 d2 = (u32)(rec.y >> 59) & 15u;
+        if (lane < 16)
+            sc[lane] = 0;
+        sk_wave_fence();
+        if (have)
+            atomicAdd(&sc[d2], len);
+        sk_wave_fence();
+        const u32 cnt = lane < 16 ? sc[lane] : 0u;
+        const u32 sbv = row16_excl_scan(cnt);              // lanes 0..15: where d2 = lane starts in the stage
+        const u32 n_keys = (u32)__builtin_amdgcn_readlane((int)(sbv + cnt), 15);
+        u32 adjv = 0;                                      // destination of stage slot s of d2 = lane: adjv + s
+        if (lane < 16) {
+            scur[lane] = sbv;
+            adjv = kb + nbase[lane] + done[lane] - sbv;
+            done[lane] += cnt;
+        }
+        sk_wave_fence();
+        if (have && !(dbg & 8)) {
+            const u32 o = atomicAdd(&scur[d2], len);
+            const u64 hi = rec.y & (((u64)1 << 44) - 1);
+            for (u32 j = 0; j < len; j++)
+                stage[o + j] = funnel(rec.x, hi, 2 * j) & kmask;
+        }
+        sk_wave_fence();
+        if (dbg & 16)
+            continue;
+        // copy out group by group: bounds and destination offsets as scalars, a group is rarely longer than 64 keys
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const u32 g0 = (u32)__builtin_amdgcn_readlane((int)sbv, g);
+            const u32 g1 = g < 15 ? (u32)__builtin_amdgcn_readlane((int)sbv, g + 1) : n_keys;
+            const u32 a = (u32)__builtin_amdgcn_readlane((int)adjv, g);
+            for (u32 s = g0 + lane; s < g1; s += 64)
+                __builtin_nontemporal_store(stage[s], &keys[(u64)(a + s)]);
+        }
+        sk_wave_fence();                                   // the stage and adj are rewritten by the next batch
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sk_regroup: inside every mid bucket the records are regrouped by d2 (16 final buckets), from one record buffer
+// into the same range of the other: a workgroup per mid bucket counts d2 (records and k-mers), then copies tile
+// by tile with the same index staging as sk_scatter1.  out_nodes[16 i + j] = final bucket j of mid bucket i:
+// start / len in RECORDS, child_base = its k-mers.
+constexpr int SKR_NT = 1024;
+constexpr int SKR_ITEMS = 8;
+constexpr int SKR_TILE = SKR_NT * SKR_ITEMS;
+__global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restrict__ mids, u32 n_mids,
+                                                            const ull2_t *__restrict__ src_all, ull2_t *__restrict__ dst_all,
+                                                            Node *__restrict__ out_nodes)
+{
+    __shared__ u32 rc[64][17], kc[64][17];        // per-lane copies of the 16 record / k-mer counters
+    __shared__ u32 gpos[16], tcnt[17];
+    __shared__ unsigned short idx[SKR_TILE];
     const u32 i = blockIdx.x;
     if (i >= n_mids)
         return;
     const int tid = threadIdx.x, lane = tid & 63;
     const Node nd = mids[i];
-    const u64 kmask = kmer_mask(k);
-    const ull2_t *src = recs + (u64)nd.start;
-    for (int q = tid; q < 64 * 17; q += SKX_NT)
+    const ull2_t *src = src_all + (u64)nd.start;
+    for (int q = tid; q < 64 * 17; q += SKR_NT) {
+        (&rc[0][0])[q] = 0;
         (&kc[0][0])[q] = 0;
-    if (tid < 16)
-        done[tid] = 0;
-    __syncthreads();
-    for (u32 r = tid; r < nd.len; r += SKX_NT) {
-        const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
-        atomicAdd(&kc[lane][(u32)(m >> 59) & 15u], (u32)((m >> 44) & 31) + 1u);
     }
     __syncthreads();
-    if (tid < 16) {
-        u32 s = 0;
+    for (u32 r = tid; r < nd.len; r += SKR_NT) {
+        const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
+        const u32 d2 = (u32)(m >> 59) & 15u;
+        atomicAdd(&rc[lane][d2], 1u);
+        atomicAdd(&kc[lane][d2], (u32)((m >> 44) & 31) + 1u);
+    }
+    __syncthreads();
+    if (tid < 32) {                                // threads 0..15: records, 16..31: k-mers of d2 = tid % 16
+        const u32 (*tab)[17] = tid < 16 ? rc : kc;
+        u32 sum = 0;
         for (int q = 0; q < 64; q++)
-            s += kc[q][tid];
-        sc[tid] = s;
+            sum += tab[q][tid & 15];
+        tcnt[tid & 15] = 0;                        // (benign: both halves store 0)
+        if (tid < 16)
+            rc[0][tid] = sum;
+        else
+            kc[0][tid & 15] = sum;
     }
     __syncthreads();
     if (tid == 0) {
         u32 run = 0;
         for (int j = 0; j < 16; j++) {
-            nbase[j] = run;
-            run += sc[j];
+            gpos[j] = nd.start + run;
+            Node o;
+            o.start = nd.start + run;
+            o.len = rc[0][j];
+            o.meta = 0;
+            o.split = 0;
+            o.prefix = 0;
+            o.child_base = kc[0][j];
+            o.chunk_base = 0;
+            out_nodes[(u64)i * 16 + j] = o;
+            run += rc[0][j];
         }
-        nbase[16] = run;
     }
     __syncthreads();
-    const u32 kb = key_base[i];
-    if (tid < 16) {
-        Node o;
-        o.start = kb + nbase[tid];
-        o.len = nbase[tid + 1] - nbase[tid];
-        o.meta = (u32)(2 * k);                    // no key bit is fixed: the leaves sort on the top bits; buffer 0
-        o.split = 0;
-        o.prefix = 0;
-        o.child_base = 0;
-        o.chunk_base = 0;
-        out_nodes[(u64)i * 16 + tid] = o;
-    }
-    for (u32 b0 = 0; b0 < nd.len; b0 += SKX_NT) {
-        if (tid < 16) {
-            sc[tid] = 0;
+    for (u32 t0 = 0; t0 < nd.len; t0 += SKR_TILE) {
+        const u32 n_tile = nd.len - t0 < (u32)SKR_TILE ? nd.len - t0 : (u32)SKR_TILE;
+        u32 dig[SKR_ITEMS], rank[SKR_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 r = tid + j * SKR_NT;
+            dig[j] = 0;
+            rank[j] = 0;
+            if (r < n_tile) {
+                const u64 m = reinterpret_cast<const u64 *>(src + t0 + r)[1];
+                dig[j] = (u32)(m >> 59) & 15u;
+                rank[j] = atomicAdd(&tcnt[dig[j]], 1u);      // (16 hot addresses: the tile's share of this is small)
+            }
         }
         __syncthreads();
-        const u32 r = b0 + tid;
-        ull2_t rec;
-        rec.x = 0;
-        rec.y = 0;
-        u32 len = 0, d2 = 0;
-        if (r < nd.len) {
-            rec = src[r];
-            len = (u32)((rec.y >> 44) & 31) + 1u;
-            d2 = (u32)(rec.y >> 59) & 15u;
-            atomicAdd(&sc[d2], len);
-        }
-        __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {                             // counts -> exclusive offsets, tcnt[16] = n_tile
             u32 run = 0;
             for (int j = 0; j < 16; j++) {
-                sb[j] = run;
-                scur[j] = run;
-                run += sc[j];
+                const u32 c = tcnt[j];
+                tcnt[j] = run;
+                run += c;
             }
-            sb[16] = run;
+            tcnt[16] = run;
         }
         __syncthreads();
-        if (len) {
-            u32 o = atomicAdd(&scur[d2], len);
-            const u64 hi = rec.y & (((u64)1 << 44) - 1);
-            for (u32 j = 0; j < len; j++)
-                stage[o + j] = funnel(rec.x, hi, 2 * j) & kmask;
-        }
-        __syncthreads();
-        const u32 n_keys = sb[16];
-        for (u32 s = tid; s < n_keys; s += SKX_NT) {
-            u32 j = 0;
 #pragma unroll
-            for (int q = 1; q < 16; q++)
-                j += s >= sb[q] ? 1u : 0u;
-            __builtin_nontemporal_store(stage[s], &keys[(u64)kb + nbase[j] + done[j] + (s - sb[j])]);
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 r = tid + j * SKR_NT;
+            if (r < n_tile)
+                idx[tcnt[dig[j]] + rank[j]] = (unsigned short)r;
         }
         __syncthreads();
-        if (tid < 16)
-            done[tid] += sc[tid];
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 s = tid + j * SKR_NT;
+            if (s < n_tile) {
+                const ull2_t r = src[t0 + idx[s]];
+                const u32 d = (u32)(r.y >> 59) & 15u;
+                __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s - tcnt[d])]);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            gpos[tid] += tcnt[tid + 1] - tcnt[tid];
+            tcnt[tid] = 0;
+        }
         __syncthreads();
     }
 }
 
+hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s)
+{
+    if (n_mids == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_regroup_kernel, dim3(n_mids), dim3(SKR_NT), 0, s, mids, n_mids, reinterpret_cast<const ull2_t *>(src),
+                       reinterpret_cast<ull2_t *>(dst), out_nodes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sk_count: the leaves of the super-k-mer engine.  A final bucket of at most SKC_CAP k-mers in at most SKC_MAXREC
+// records is counted straight from its records in the workgroup's LDS hash table (linear probing, 64-bit
+// compare-and-swap, 16-bit counts beside it -- the table of hash_leaves_kernel); then the table is emitted
+// slot-chunk by slot-chunk with ballots and cleaned on the way.  No key of such a bucket ever reaches HBM.
+//   The k-mers are spread evenly over the threads (eight consecutive ones each): a prefix sum over the record
+//   lengths (one record per thread) tells every thread, by binary search, in which record its first k-mer lies.
+//   One thread per RECORD instead would leave two lanes in three idle (runs are 1..17 k-mers long).
+// Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
+constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
+constexpr int SKC_SLOTS = 124 * 64;              // 7936 slots: with counts and the prefix table 79.6 KiB, two workgroups per CU
+constexpr int SKC_MAXREC = SKC_NT;               // one record per thread in the prefix sum
+constexpr int SKC_KPT = 4;                       // k-mers per thread: SKC_NT * SKC_KPT = the 4096 of sk_count_cap()
+constexpr u64 SKC_EMPTY = ~(u64)0;
+
+__global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
+                                                             u32 n_list, const ull2_t *__restrict__ recs, int k,
+                                                             unsigned long long *__restrict__ cursor,
+                                                             u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                             u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
+{
+    constexpr int WAVES = SKC_NT / 64;
+    __shared__ __attribute__((aligned(16))) u64 tab[SKC_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 cnt2[SKC_SLOTS / 2];
+    unsigned short *cnt16 = reinterpret_cast<unsigned short *>(cnt2);
+    __shared__ unsigned short pre[SKC_MAXREC + 2];   // exclusive prefix of the records' k-mer counts
+    __shared__ u32 wclaim[2][WAVES], wlen[WAVES];
+    __shared__ u64 sh_obase[2];
+    __shared__ u32 ones_cnt[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 lq = blockIdx.x;
+    if (lq >= n_list)
+        return;
+    for (int q = tid; q < SKC_SLOTS; q += SKC_NT)
+        tab[q] = SKC_EMPTY;
+    for (int q = tid; q < SKC_SLOTS / 2; q += SKC_NT)
+        cnt2[q] = 0;
+    if (tid < 2)
+        ones_cnt[tid] = 0;
+    const u64 kmask = kmer_mask(k);
+    const u64 below = ((u64)1 << lane) - 1;
+    u32 li = list[lq];
+    Node nd = fin[li];
+    // the lengths of this thread's two records (records tid and tid + SKC_NT); the next bucket's are requested early
+    u64 m0 = 0;
+    if ((u32)tid < nd.len)
+        m0 = reinterpret_cast<const u64 *>(recs + (u64)nd.start + tid)[1];
+
+    // What a thread keeps of a bucket until its output range has arrived (the range is requested from the global
+    // cursor when the bucket's inserts are done and used one bucket later: nobody waits for that atomic): the keys
+    // whose slots it claimed, their counts, the ballots' worth of positions.
+    u64 pk[SKC_KPT];
+    u32 pc[SKC_KPT];
+    u32 p_mask = 0, p_before = 0, p_groups = 0, p_ones = 0, p_li = 0;
+    u64 ob_pending = 0;
+    bool have_prev = false;
+    int par = 0;
+
+    auto emit_prev = [&](int pp) {
+        // every wave's claimed keys go out position by position: lanes that claimed their q-th key write one
+        // contiguous run per store instruction
+        const u64 obase = sh_obase[pp];
+        u32 run = p_before;
+#pragma unroll
+        for (int q = 0; q < SKC_KPT; q++) {
+            const bool mine = (p_mask >> q) & 1u;
+            const u64 b = __ballot(mine);
+            if (mine) {
+                const u64 o = obase + run + (u32)__popcll(b & below);
+                out_keys[o] = pk[q];
+                out_counts[o] = pc[q];
+            }
+            run += (u32)__popcll(b);
+        }
+        if (p_ones && tid == 0) {
+            out_keys[obase + p_groups - 1] = SKC_EMPTY;
+            out_counts[obase + p_groups - 1] = p_ones;
+        }
+        if (tid == 0) {
+            seg_off[p_li] = obase;
+            seg_cnt[p_li] = p_groups;
+        }
+    };
+
+    for (;;) {
+        const u32 lq_next = lq + gridDim.x;
+        const bool has_next = lq_next < n_list;
+        const u32 ln = has_next ? list[lq_next] : li;
+        const Node nn = fin[ln];
+        // ---- prefix over the record lengths (one record per thread)
+        const u32 l0 = (u32)tid < nd.len ? (u32)((m0 >> 44) & 31) + 1u : 0u;
+        const u32 i0 = wave_incl_scan(l0);
+        if (lane == 63)
+            wlen[wave] = i0;
+        __syncthreads();                           // A (also: every slot claimed for the previous bucket has been reset)
+        u32 b0 = 0, n_k = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            const u32 t0 = wlen[w];
+            b0 += w < wave ? t0 : 0u;
+            n_k += t0;
+        }
+        pre[tid] = (unsigned short)(b0 + i0 - l0);
+        __syncthreads();                           // A2: pre[] complete
+        if (has_next) {
+            m0 = 0;
+            if ((u32)tid < nn.len)
+                m0 = reinterpret_cast<const u64 *>(recs + (u64)nn.start + tid)[1];
+        }
+        // ---- this thread's k-mers: [SKC_KPT * tid, + SKC_KPT) of the bucket's n_k
+        u64 ck[SKC_KPT];
+        u32 cslot[SKC_KPT];
+        u32 c_mask = 0;
+        const u32 kfirst = (u32)tid * SKC_KPT;
+        if (kfirst < n_k) {
+            // last record r with pre[r] <= kfirst (records past the bucket's end have pre = n_k > kfirst)
+            u32 lo = 0, hi = nd.len - 1;
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if ((u32)pre[mid] <= kfirst)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            u32 r = lo;
+            u32 j = kfirst - (u32)pre[r];
+            const ull2_t *rp = recs + (u64)nd.start;
+            ull2_t rec = rp[r], rec1, rec2;
+            rec1.x = rec1.y = rec2.x = rec2.y = 0;
+            if (r + 1 < nd.len)
+                rec1 = rp[r + 1];
+            if (r + 2 < nd.len)
+                rec2 = rp[r + 2];
+            u32 len = (u32)((rec.y >> 44) & 31) + 1u;
+            // the record's bases from k-mer j on, shifted down two bits per k-mer
+            u64 slo = funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j), shi = (rec.y & (((u64)1 << 44) - 1)) >> (2 * j);
+#pragma unroll
+            for (int q = 0; q < SKC_KPT; q++) {
+                ck[q] = 0;
+                cslot[q] = 0;
+                if (kfirst + (u32)q < n_k) {
+                    if (j == len) {                // on to the next record (two more are always loaded)
+                        r++;
+                        j = 0;
+                        rec = rec1;
+                        rec1 = rec2;
+                        if (r + 2 < nd.len)
+                            rec2 = rp[r + 2];
+                        len = (u32)((rec.y >> 44) & 31) + 1u;
+                        slo = rec.x;
+                        shi = rec.y & (((u64)1 << 44) - 1);
+                    }
+                    const u64 kv = slo & kmask;
+                    slo = (slo >> 2) | (shi << 62);
+                    shi >>= 2;
+                    j++;
+                    if (kv == SKC_EMPTY) {
+                        atomicAdd(&ones_cnt[par], 1u);
+                    } else {
+                        u32 slot = (((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 16) * (u32)SKC_SLOTS) >> 16;
+                        for (;;) {
+                            const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
+                                                      (unsigned long long)SKC_EMPTY, (unsigned long long)kv);
+                            if (old == SKC_EMPTY) {
+                                c_mask |= 1u << q;
+                                ck[q] = kv;
+                                cslot[q] = slot;
+                                break;
+                            }
+                            if (old == kv)
+                                break;
+                            slot = slot + 1 == (u32)SKC_SLOTS ? 0u : slot + 1;
+                        }
+                        atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
+                    }
+                }
+            }
+        }
+        const u32 wc = wave_sum((u32)__popc(c_mask));
+        if (lane == 0)
+            wclaim[par][wave] = wc;
+        if (tid == 0 && have_prev)
+            sh_obase[par ^ 1] = ob_pending;        // (requested one bucket ago: the wait for it ends here at the latest)
+        __syncthreads();                           // B: all inserts done; the previous bucket's range is known
+        if (have_prev)
+            emit_prev(par ^ 1);
+        // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
+        u32 before = 0, D = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            const u32 t = wclaim[par][w];
+            before += w < wave ? t : 0u;
+            D += t;
+        }
+#pragma unroll
+        for (int q = 0; q < SKC_KPT; q++) {
+            pk[q] = ck[q];
+            pc[q] = 0;
+            if ((c_mask >> q) & 1u) {
+                pc[q] = cnt16[cslot[q]];
+                tab[cslot[q]] = SKC_EMPTY;
+                cnt16[cslot[q]] = 0;
+            }
+        }
+        p_mask = c_mask;
+        p_before = before;
+        p_ones = ones_cnt[par];
+        p_groups = D + (p_ones ? 1u : 0u);
+        p_li = li;
+        if (tid == 0) {
+            ob_pending = atomicAdd(cursor, (unsigned long long)p_groups);
+            ones_cnt[par ^ 1] = 0;                 // (the other parity's counter: its bucket has been emitted)
+        }
+        have_prev = true;
+        par ^= 1;
+        if (!has_next)
+            break;
+        lq = lq_next;
+        li = ln;
+        nd = nn;
+    }
+    // the last bucket's output
+    if (tid == 0)
+        sh_obase[par ^ 1] = ob_pending;
+    __syncthreads();
+    emit_prev(par ^ 1);
+}
+
+hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const void *recs, int k, u64 *cursor, u64 *seg_off,
+                           u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
+{
+    if (n_list == 0)
+        return hipSuccess;
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
+    hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, n_list, reinterpret_cast<const ull2_t *>(recs),
+                       k, reinterpret_cast<unsigned long long *>(cursor), seg_off, seg_cnt, out_keys, out_counts);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// selection of the final buckets: those of at most `cap` k-mers are counted from their records (list_small); the
+// others are expanded to keys for the ordinary levels (compact copies in over_nodes, their key ranges in over_kbase)
+__global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
+                                                              u32 *__restrict__ f_small, u32 *__restrict__ f_over,
+                                                              u32 *__restrict__ k_over)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin)
+        return;
+    const u32 km = fin[i].child_base;
+    const bool small = km <= cap && fin[i].len <= (u32)SKC_MAXREC;
+    f_small[i] = km > 0 && small ? 1u : 0u;
+    f_over[i] = km > 0 && !small ? 1u : 0u;
+    k_over[i] = km > 0 && !small ? km : 0u;
+}
+
+__global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
+                                                              const u32 *__restrict__ p_small, const u32 *__restrict__ p_over,
+                                                              const u32 *__restrict__ kb_over, u32 *__restrict__ list_small,
+                                                              Node *__restrict__ over_nodes, u32 *__restrict__ over_kbase)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin)
+        return;
+    const Node nd = fin[i];
+    const u32 km = nd.child_base;
+    const bool small = km <= cap && nd.len <= (u32)SKC_MAXREC;
+    if (km > 0 && small)
+        list_small[p_small[i]] = i;
+    if (km > 0 && !small) {
+        over_nodes[p_over[i]] = nd;
+        over_kbase[p_over[i]] = kb_over[i];
+    }
+}
+
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, hipStream_t s)
+{
+    if (n_fin == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_select_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, f_small, f_over,
+                       k_over);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
+                                  u32 *list_small, Node *over_nodes, u32 *over_kbase, hipStream_t s)
+{
+    if (n_fin == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_select_lists_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, p_small, p_over,
+                       kb_over, list_small, over_nodes, over_kbase);
+    return hipGetLastError();
+}
+
+// timing ablations (results invalid): diagnostic build (make STAMPS=1) only
+static int sk_dbg()
+{
+#ifdef DNAGPU_STAMPS
+    const char *e = getenv("DNAGPU_DEBUG_SK");
+    return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
+static bool g_sk_attr_done = false;               // (set per call: the attribute is per device and cheap to set)
 template <int W>
 static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk *chunks, const u64 *words, u64 n_words,
                          u64 first, int k, u32 lmax, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs)
 {
     if (scatter)
         hipLaunchKernelGGL(sk_scatter0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           k, lmax, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs));
+                           k, lmax, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg());
     else
         hipLaunchKernelGGL(sk_hist0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
                            lmax, c0n, b1mask, r0n, hist);
@@ -559,6 +1075,8 @@ hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, con
     if (lmax > 32)
         lmax = 32;
     const u32 b1mask = (1u << b1bits) - 1, r0n = 1u << r0bits;
+    if (r0n > (u32)SK_MAX_C0)
+        return hipErrorInvalidValue;
 #define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, c0n, b1mask, r0n, hist, tot, recs); break;
     switch (w) {
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16) SK_CASE(17) SK_CASE(18)
@@ -593,8 +1111,19 @@ hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, cons
 {
     if (n_mids == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_expand_kernel, dim3(n_mids), dim3(SKX_NT), 0, s, mids, n_mids, reinterpret_cast<const ull2_t *>(recs),
-                       key_base, k, keys, out_nodes);
+    u32 lmax = (u32)(54 - k + 1);
+    if (lmax > 32)
+        lmax = 32;
+    const size_t smem = (size_t)SKX_WAVES * ((size_t)64 * lmax * 8 + 5 * 16 * 4);
+    if (!g_sk_attr_done) {        // (the same value for every k: the largest stage)
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)SKX_WAVES * ((size_t)64 * 32 * 8 + 5 * 16 * 4)));
+        if (ae != hipSuccess)
+            return ae;
+    }
+    hipLaunchKernelGGL(sk_expand_kernel, dim3((n_mids + SKX_WAVES - 1) / SKX_WAVES), dim3(SKX_NT), smem, s, mids, n_mids,
+                       reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax, keys, out_nodes, sk_dbg());
     return hipGetLastError();
 }
 
