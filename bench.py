@@ -48,12 +48,23 @@ PHASE_BYTES = {
     "scatter": lambda n, d, N: 16.0 * n,            # keys in, keys out
     "leaves": lambda n, d, N: 8.0 * n + 12.0 * d,   # keys in, (u64 key, u32 count) groups out
     "dense": lambda n, d, N: 0.25 * N,              # short k-mers: the packed input per pass
+    # super-k-mer engine (dnagpu_count_kmers_unordered, k >= 23): 16-byte records of ~9 k-mers (runs sharing a
+    # minimizer; mean run length (w + 1) / 2 at window w = k - 14) instead of 8-byte keys
+    "sk_hist0": lambda n, d, N: 0.25 * N,
+    "sk_scatter0": lambda n, d, N: 0.25 * N + 16.0 * n / SK_RUN,
+    "sk_hist1": lambda n, d, N: 16.0 * n / SK_RUN,
+    "sk_scatter1": lambda n, d, N: 32.0 * n / SK_RUN,
+    "sk_regroup": lambda n, d, N: 32.0 * n / SK_RUN,
+    "sk_count": lambda n, d, N: 16.0 * n / SK_RUN + 12.0 * d,   # records in, (u64 key, u32 count) groups out
 }
+SK_RUN = 9.0   # k-mers per record at k = 31 (window of 17 m-mers); set per run from k in main()
 
 
 def phase_kind(name):
     if name == "leaves":
         return "leaves"
+    if name in PHASE_BYTES and name.startswith("sk_"):
+        return name
     if name.endswith("_hist"):
         return "hist0" if name.startswith("level0") else "hist"
     if name.endswith("_scatter"):
@@ -74,6 +85,10 @@ def main():
     ap.add_argument("--motif", type=int, default=0,
                     help="repeat-rich variant (SURVEY.md 8(d)): tile the first MOTIF bases over the second half")
     ap.add_argument("--pattern", type=str, default=None, help="config 5: the qkmer pattern (length k)")
+    ap.add_argument("--engine", choices=["auto", "tree"], default="auto",
+                    help="count configs: auto = dnagpu_count_kmers_unordered (GROUP BY semantics: group order "
+                         "unspecified; super-k-mer partitioning for k >= 23 on long sequences), tree = "
+                         "dnagpu_count_kmers (groups in ascending key order, MSD radix tree)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,6 +104,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_bases, k, seed = cfg["n_bases"], cfg["k"], cfg["seed"]
     n_kmers = n_bases - k + 1
+    global SK_RUN
+    SK_RUN = (max(k - 14, 1) + 1) / 2.0
     is_filter = cfg["kind"] == "filter"
     if is_filter and world > 1:
         raise SystemExit("config 5 is a single-GPU workload (BASELINE.json)")
@@ -125,6 +142,7 @@ def main():
     distinct = [0]
     matches = [0]
     extra = {}
+    sorted_result = [True]
 
     if is_filter:
         import ctypes as C
@@ -140,8 +158,11 @@ def main():
     elif world == 1:
         dna = ctx.synth(seed, n_bases, motif_len=args.motif)
 
+        count_fn = ctx.count_kmers if args.engine == "tree" else ctx.count_kmers_unordered
+
         def step():
-            h = ctx.count_kmers(dna, k)
+            h = count_fn(dna, k)
+            sorted_result[0] = h.is_sorted
             distinct[0] = h.distinct
             for name, ms in ctx.last_phase_times():
                 phases_acc.setdefault(name, []).append(ms)
@@ -181,7 +202,11 @@ def main():
         dist.all_reduce(dsum)
         distinct[0] = int(dsum.item())
 
-    if rank == 0 and world == 1 and not is_filter:
+    if rank == 0 and world == 1 and not is_filter and not sorted_result[0]:
+        extra["sorted_view_ms"] = None
+        extra["group_order"] = ("unspecified (bucket order of the super-k-mer engine; PostgreSQL's GROUP BY order is "
+                                "unspecified too, test.sql:95-104); --engine tree gives ascending keys")
+    elif rank == 0 and world == 1 and not is_filter:
         # outside the timed region: what the ascending-key view of the same histogram costs on the device
         # (dnagpu_hist_sorted_view: segment directory -> two dense uint64 arrays); groups are stored in
         # completion order, PostgreSQL's GROUP BY order is unspecified too (test.sql:95-104)
@@ -250,8 +275,9 @@ def main():
                    "alg_bytes_per_kmer": round((b_in + 16 * distinct[0]) / n_kmers, 3)}
             metric = HEADLINE_METRIC if args.config == 4 else \
                 f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline"
+            eng = "" if world > 1 else (", ordered groups (MSD radix tree)" if sorted_result[0] else ", unordered groups (super-k-mer partitioning)")
             workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}"
-                        f"{', motif ' + str(args.motif) if args.motif else ''}), "
+                        f"{', motif ' + str(args.motif) if args.motif else ''}){eng}, "
                         f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-gather of the packed sequence + owner-filtered count'}")
             unit = "k-mers/s"
         line = {

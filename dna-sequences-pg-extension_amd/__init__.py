@@ -11,6 +11,7 @@ The directory name has a hyphen (it mirrors the reference's name), so it is load
 ``__graft_entry__.load_package()`` under the module name ``dna_sequences_pg_extension_amd``.
 """
 from .binding import (  # noqa: F401
+    DEBUG_FORCE_SUPERKMER,
     Context,
     Dna,
     DnaGpuError,

@@ -21,6 +21,7 @@ ERR_HIP = 9
 ERR_DNA_EMPTY = 11
 ERR_DNA_INVALID_CHAR = 12
 DEBUG_POISON_POOL = 1
+DEBUG_FORCE_SUPERKMER = 2
 
 FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2
@@ -268,11 +269,13 @@ class Context:
         _chk(lib().dnagpu_init(device, C.byref(self.h)))
         # test harness switch (this wrapper is test/bench tooling): DNAGPU_TEST_POISON=1 runs every context
         # with DNAGPU_DEBUG_POISON_POOL, i.e. all work buffers pre-filled with 0xFF
-        if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0"):
-            self.set_debug(DEBUG_POISON_POOL)
+        self._base_debug = DEBUG_POISON_POOL if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0") else 0
+        if self._base_debug:
+            self.set_debug(0)
 
     def set_debug(self, flags):
-        _chk(lib().dnagpu_set_debug(self.h, int(flags)))
+        """flags on top of what the environment asked for"""
+        _chk(lib().dnagpu_set_debug(self.h, int(flags) | self._base_debug))
 
     def close(self):
         if self.h:

@@ -1236,7 +1236,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 // DNAGPU_SK_SKEWED: a bucket is too heavy (low-complexity input): the caller counts with the ordinary tree
 // instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
-constexpr u64 SK_LEAF_MEAN = 3300;               // planned k-mers per final bucket: 4096 (the hash leaf's capacity) is > 3 sigma above
+constexpr u64 SK_LEAF_MEAN = 2900;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
 constexpr u64 SK_MID_LIMIT = (u64)1 << 21;       // most k-mers one mid bucket may hold (planned: 16 x SK_LEAF_MEAN)
 
 struct SkLevel {                                 // what one forced partition level leaves behind
@@ -1342,12 +1342,7 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     prof_mark(ctx, "sk_prefix1");
     HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, c0n, (u32)chunk_recs, l1.hist, l1.tot, st));
     HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
-    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
-    ps.ptrs.push_back(rec1);
-    prof_mark(ctx, "sk_scatter1");
-    HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
-
-    // ---- skew check on the k-mers per mid bucket (the list is short: host)
+    // ---- skew check on the k-mers per mid bucket, before their records move (the list is short: host)
     std::vector<u32> kc(l1.n_next);
     HIP_TRY(hipMemcpyAsync(kc.data(), kcount, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1362,6 +1357,11 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     }
     if (heaviest > SK_MID_LIMIT)
         return DNAGPU_SK_SKEWED;
+
+    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
+    ps.ptrs.push_back(rec1);
+    prof_mark(ctx, "sk_scatter1");
+    HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
 
     // ---- level 2: every mid bucket regrouped by d2 (rec1 -> rec0): 16 final buckets each
     Node *fn = nullptr;
@@ -1472,6 +1472,9 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
 // any_order: the caller does not need ascending keys across the whole result (dnagpu_count_kmers_unordered): long
 // k-mers of long sequences then go through the super-k-mer engine
 constexpr u64 SK_MIN_ROWS = (u64)1 << 22;
+// the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record): measured at 1 Gbase, k = 27 is 5 %
+// slower than the tree, k = 31 4 % faster (10 % at 3 Gbase)
+constexpr int SK_MIN_K = 29;
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
                       bool any_order = false)
@@ -1488,7 +1491,8 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     prof_begin(ctx);
     int rc;
     bool sorted = true;                          // segments in ascending key order (false: bucket order of the super-k-mer engine)
-    if (any_order && dna && fixed_bits == 0 && n_owners == 1 && k >= sk_min_k() && n >= SK_MIN_ROWS) {
+    const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && n >= 64;
+    if (any_order && dna && fixed_bits == 0 && n_owners == 1 && ((k >= SK_MIN_K && n >= SK_MIN_ROWS) || force_sk)) {
         rc = count_sk(ctx, dna, first, n, k, h);
         if (rc != DNAGPU_SK_SKEWED) {
             prof_end(ctx);

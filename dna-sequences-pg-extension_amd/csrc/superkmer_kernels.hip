@@ -622,7 +622,7 @@ __global__ __launch_bounds__(SKX_NT) void sk_expand_kernel(const Node *__restric
 // sk_regroup: inside every mid bucket the records are regrouped by d2 (16 final buckets), from one record buffer
 // into the same range of the other: a workgroup per mid bucket counts d2 (records and k-mers), then copies tile
 // by tile with the same index staging as sk_scatter1.  out_nodes[16 i + j] = final bucket j of mid bucket i:
-// start / len in RECORDS, child_base = its k-mers.
+// start / len in RECORDS, child_base = its k-mers, chunk_base = its quads (sk_count's work items).
 constexpr int SKR_NT = 1024;
 constexpr int SKR_ITEMS = 8;
 constexpr int SKR_TILE = SKR_NT * SKR_ITEMS;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
                                                             const ull2_t *__restrict__ src_all, ull2_t *__restrict__ dst_all,
                                                             Node *__restrict__ out_nodes)
 {
-    __shared__ u32 rc[64][17], kc[64][17];        // per-lane copies of the 16 record / k-mer counters
+    __shared__ u32 rc[64][17], kc[64][17], qc[64][17];   // per-lane copies of the 16 record / k-mer / quad counters
     __shared__ u32 gpos[16], tcnt[17];
     __shared__ unsigned short idx[SKR_TILE];
     const u32 i = blockIdx.x;
@@ -642,25 +642,30 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
     for (int q = tid; q < 64 * 17; q += SKR_NT) {
         (&rc[0][0])[q] = 0;
         (&kc[0][0])[q] = 0;
+        (&qc[0][0])[q] = 0;
     }
     __syncthreads();
     for (u32 r = tid; r < nd.len; r += SKR_NT) {
         const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
         const u32 d2 = (u32)(m >> 59) & 15u;
+        const u32 len = (u32)((m >> 44) & 31) + 1u;
         atomicAdd(&rc[lane][d2], 1u);
-        atomicAdd(&kc[lane][d2], (u32)((m >> 44) & 31) + 1u);
+        atomicAdd(&kc[lane][d2], len);
+        atomicAdd(&qc[lane][d2], (len + 3u) >> 2);   // quads of sk_count: groups of four k-mers of one record
     }
     __syncthreads();
-    if (tid < 32) {                                // threads 0..15: records, 16..31: k-mers of d2 = tid % 16
-        const u32 (*tab)[17] = tid < 16 ? rc : kc;
+    if (tid < 48) {                                // threads 0..15: records, 16..31: k-mers, 32..47: quads of d2 = tid % 16
+        const u32 (*tab)[17] = tid < 16 ? rc : (tid < 32 ? kc : qc);
         u32 sum = 0;
         for (int q = 0; q < 64; q++)
             sum += tab[q][tid & 15];
-        tcnt[tid & 15] = 0;                        // (benign: both halves store 0)
+        tcnt[tid & 15] = 0;                        // (benign: all three store 0)
         if (tid < 16)
             rc[0][tid] = sum;
-        else
+        else if (tid < 32)
             kc[0][tid & 15] = sum;
+        else
+            qc[0][tid & 15] = sum;
     }
     __syncthreads();
     if (tid == 0) {
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
             o.split = 0;
             o.prefix = 0;
             o.child_base = kc[0][j];
-            o.chunk_base = 0;
+            o.chunk_base = qc[0][j];
             out_nodes[(u64)i * 16 + j] = o;
             run += rc[0][j];
         }
@@ -740,32 +745,37 @@ hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void
 }
 
 // ------------------------------------------------------------------------------------------------
-// sk_count: the leaves of the super-k-mer engine.  A final bucket of at most SKC_CAP k-mers in at most SKC_MAXREC
-// records is counted straight from its records in the workgroup's LDS hash table (linear probing, 64-bit
-// compare-and-swap, 16-bit counts beside it -- the table of hash_leaves_kernel); then the table is emitted
-// slot-chunk by slot-chunk with ballots and cleaned on the way.  No key of such a bucket ever reaches HBM.
-//   The k-mers are spread evenly over the threads (eight consecutive ones each): a prefix sum over the record
-//   lengths (one record per thread) tells every thread, by binary search, in which record its first k-mer lies.
-//   One thread per RECORD instead would leave two lanes in three idle (runs are 1..17 k-mers long).
+// sk_count: the leaves of the super-k-mer engine.  A final bucket of at most sk_count_cap() k-mers in at most
+// SKC_MAXREC records is counted straight from its records in the workgroup's LDS hash table (linear probing, 64-bit
+// compare-and-swap; copies of a key are counted in 16-bit halves beside it); the keys a thread was first to insert
+// stay in its registers and leave, with their counts, when the bucket's output range has arrived.  No key of such a
+// bucket ever reaches HBM as a key.
+//   Work split: a record's k-mers are cut into groups of SKC_KPT ("quads"); a prefix sum over the records' quad counts
+//   gives every quad a thread, and every record writes its quads' owner entries itself -- no search.  Records and
+//   owner table live in LDS, so that nothing between two barriers waits for global memory: the next bucket's records
+//   are requested a whole bucket ahead, the output range (one atomic add on the global cursor) one bucket behind.
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
-constexpr int SKC_SLOTS = 124 * 64;              // 7936 slots: with counts and the prefix table 79.6 KiB, two workgroups per CU
-constexpr int SKC_MAXREC = SKC_NT;               // one record per thread in the prefix sum
-constexpr int SKC_KPT = 4;                       // k-mers per thread: SKC_NT * SKC_KPT = the 4096 of sk_count_cap()
+constexpr int SKC_SLOTS = 106 * 64;              // 6784 slots (load 0.49 at 3300 keys): with the tables below 79.9 KiB, two workgroups per CU
+constexpr int SKC_MAXREC = 512;                  // records of a bucket (a bucket of 3300 k-mers of random sequence has ~370)
+constexpr int SKC_KPT = 4;                       // k-mers per quad
+constexpr int SKC_MAXQ = SKC_NT;                 // quads of a bucket: one per thread (the selection sends buckets with more elsewhere)
 constexpr u64 SKC_EMPTY = ~(u64)0;
 
 __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
                                                              u32 n_list, const ull2_t *__restrict__ recs, int k,
                                                              unsigned long long *__restrict__ cursor,
                                                              u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
-                                                             u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
+                                                             u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, int dbg)
 {
     constexpr int WAVES = SKC_NT / 64;
+    constexpr int RWAVES = SKC_MAXREC / 64;        // waves that hold records
     __shared__ __attribute__((aligned(16))) u64 tab[SKC_SLOTS];
     __shared__ __attribute__((aligned(16))) u32 cnt2[SKC_SLOTS / 2];
     unsigned short *cnt16 = reinterpret_cast<unsigned short *>(cnt2);
-    __shared__ unsigned short pre[SKC_MAXREC + 2];   // exclusive prefix of the records' k-mer counts
-    __shared__ u32 wclaim[2][WAVES], wlen[WAVES];
+    __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
+    __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
+    __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
     __shared__ u64 sh_obase[2];
     __shared__ u32 ones_cnt[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -782,16 +792,16 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     const u64 below = ((u64)1 << lane) - 1;
     u32 li = list[lq];
     Node nd = fin[li];
-    // the lengths of this thread's two records (records tid and tid + SKC_NT); the next bucket's are requested early
-    u64 m0 = 0;
+    ull2_t myrec;                                  // record tid of the bucket (threads 0 .. SKC_MAXREC-1)
+    myrec.x = myrec.y = 0;
     if ((u32)tid < nd.len)
-        m0 = reinterpret_cast<const u64 *>(recs + (u64)nd.start + tid)[1];
+        myrec = recs[(u64)nd.start + tid];
 
-    // What a thread keeps of a bucket until its output range has arrived (the range is requested from the global
-    // cursor when the bucket's inserts are done and used one bucket later: nobody waits for that atomic): the keys
-    // whose slots it claimed, their counts, the ballots' worth of positions.
-    u64 pk[SKC_KPT];
-    u32 pc[SKC_KPT];
+    // What a thread keeps of a bucket until its output range has arrived: the keys of its quad whose slots it claimed,
+    // their counts, its wave's offset.
+    constexpr int KEEP = SKC_KPT;
+    u64 pk[KEEP];
+    u32 pc[KEEP];
     u32 p_mask = 0, p_before = 0, p_groups = 0, p_ones = 0, p_li = 0;
     u64 ob_pending = 0;
     bool have_prev = false;
@@ -803,10 +813,10 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u64 obase = sh_obase[pp];
         u32 run = p_before;
 #pragma unroll
-        for (int q = 0; q < SKC_KPT; q++) {
+        for (int q = 0; q < KEEP; q++) {
             const bool mine = (p_mask >> q) & 1u;
             const u64 b = __ballot(mine);
-            if (mine) {
+            if (mine && !(dbg & 64)) {
                 const u64 o = obase + run + (u32)__popcll(b & below);
                 out_keys[o] = pk[q];
                 out_counts[o] = pc[q];
@@ -828,74 +838,65 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const bool has_next = lq_next < n_list;
         const u32 ln = has_next ? list[lq_next] : li;
         const Node nn = fin[ln];
-        // ---- prefix over the record lengths (one record per thread)
-        const u32 l0 = (u32)tid < nd.len ? (u32)((m0 >> 44) & 31) + 1u : 0u;
-        const u32 i0 = wave_incl_scan(l0);
-        if (lane == 63)
-            wlen[wave] = i0;
+        // ---- records into LDS; prefix over their quad counts (record threads only)
+        const u32 len = (u32)tid < nd.len ? (u32)((myrec.y >> 44) & 31) + 1u : 0u;
+        const u32 nq = (len + SKC_KPT - 1) / SKC_KPT;
+        u32 qinc = 0;
+        if (tid < SKC_MAXREC) {
+            lrec[tid] = myrec;
+            qinc = wave_incl_scan(nq);
+            if (lane == 63)
+                wq[wave] = qinc;
+        }
         __syncthreads();                           // A (also: every slot claimed for the previous bucket has been reset)
-        u32 b0 = 0, n_k = 0;
+        u32 n_quads = 0;
+        {
+            u32 qb = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            const u32 t0 = wlen[w];
-            b0 += w < wave ? t0 : 0u;
-            n_k += t0;
-        }
-        pre[tid] = (unsigned short)(b0 + i0 - l0);
-        __syncthreads();                           // A2: pre[] complete
-        if (has_next) {
-            m0 = 0;
-            if ((u32)tid < nn.len)
-                m0 = reinterpret_cast<const u64 *>(recs + (u64)nn.start + tid)[1];
-        }
-        // ---- this thread's k-mers: [SKC_KPT * tid, + SKC_KPT) of the bucket's n_k
-        u64 ck[SKC_KPT];
-        u32 cslot[SKC_KPT];
-        u32 c_mask = 0;
-        const u32 kfirst = (u32)tid * SKC_KPT;
-        if (kfirst < n_k) {
-            // last record r with pre[r] <= kfirst (records past the bucket's end have pre = n_k > kfirst)
-            u32 lo = 0, hi = nd.len - 1;
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if ((u32)pre[mid] <= kfirst)
-                    lo = mid;
-                else
-                    hi = mid - 1;
+            for (int w = 0; w < RWAVES; w++) {
+                const u32 t = wq[w];
+                qb += w < wave ? t : 0u;
+                n_quads += t;
             }
-            u32 r = lo;
-            u32 j = kfirst - (u32)pre[r];
-            const ull2_t *rp = recs + (u64)nd.start;
-            ull2_t rec = rp[r], rec1, rec2;
-            rec1.x = rec1.y = rec2.x = rec2.y = 0;
-            if (r + 1 < nd.len)
-                rec1 = rp[r + 1];
-            if (r + 2 < nd.len)
-                rec2 = rp[r + 2];
-            u32 len = (u32)((rec.y >> 44) & 31) + 1u;
-            // the record's bases from k-mer j on, shifted down two bits per k-mer
-            u64 slo = funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j), shi = (rec.y & (((u64)1 << 44) - 1)) >> (2 * j);
+            if (tid < SKC_MAXREC) {
+                const u32 q0 = qb + qinc - nq;
+                for (u32 q = 0; q < nq; q++)
+                    ownq[q0 + q] = (unsigned short)((u32)tid | (q << 9));
+            }
+        }
+        // the next bucket's records: in flight from here on
+        if (has_next) {
+            myrec.x = myrec.y = 0;
+            if ((u32)tid < nn.len)
+                myrec = recs[(u64)nn.start + tid];
+        }
+        __syncthreads();                           // A2: lrec[] and ownq[] complete
+        // ---- this thread's quad
+        u64 ck[KEEP];
+        u32 cslot[KEEP];
+        u32 c_mask = 0;
+#pragma unroll
+        for (int q = 0; q < SKC_KPT; q++) {
+            ck[q] = 0;
+            cslot[q] = 0;
+        }
+        if ((u32)tid < n_quads) {
+            const u32 e = ownq[tid];
+            const ull2_t rec = lrec[e & 511u];
+            const u32 rl = (u32)((rec.y >> 44) & 31) + 1u;
+            const u32 j0 = (e >> 9) * SKC_KPT;
+            const u64 hi44 = rec.y & (((u64)1 << 44) - 1);
+            u64 slo = funnel(rec.x, hi44, 2 * j0), shi = hi44 >> (2 * j0);
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
-                ck[q] = 0;
-                cslot[q] = 0;
-                if (kfirst + (u32)q < n_k) {
-                    if (j == len) {                // on to the next record (two more are always loaded)
-                        r++;
-                        j = 0;
-                        rec = rec1;
-                        rec1 = rec2;
-                        if (r + 2 < nd.len)
-                            rec2 = rp[r + 2];
-                        len = (u32)((rec.y >> 44) & 31) + 1u;
-                        slo = rec.x;
-                        shi = rec.y & (((u64)1 << 44) - 1);
-                    }
+                if (j0 + (u32)q < rl) {
                     const u64 kv = slo & kmask;
                     slo = (slo >> 2) | (shi << 62);
                     shi >>= 2;
-                    j++;
-                    if (kv == SKC_EMPTY) {
+                    if (dbg & 32) {
+                        c_mask |= (kv & 1) ? 1u << q : 0u;
+                        ck[q] = kv;
+                    } else if (kv == SKC_EMPTY) {
                         atomicAdd(&ones_cnt[par], 1u);
                     } else {
                         u32 slot = (((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 16) * (u32)SKC_SLOTS) >> 16;
@@ -908,11 +909,12 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                                 cslot[q] = slot;
                                 break;
                             }
-                            if (old == kv)
+                            if (old == kv) {       // a copy of a key already in the table: only copies are counted beside it
+                                atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
                                 break;
+                            }
                             slot = slot + 1 == (u32)SKC_SLOTS ? 0u : slot + 1;
                         }
-                        atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
                     }
                 }
             }
@@ -934,13 +936,15 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             D += t;
         }
 #pragma unroll
-        for (int q = 0; q < SKC_KPT; q++) {
+        for (int q = 0; q < KEEP; q++) {
             pk[q] = ck[q];
             pc[q] = 0;
             if ((c_mask >> q) & 1u) {
-                pc[q] = cnt16[cslot[q]];
+                const u32 copies = cnt16[cslot[q]];
+                pc[q] = 1u + copies;
                 tab[cslot[q]] = SKC_EMPTY;
-                cnt16[cslot[q]] = 0;
+                if (copies)
+                    cnt16[cslot[q]] = 0;
             }
         }
         p_mask = c_mask;
@@ -967,6 +971,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     emit_prev(par ^ 1);
 }
 
+static int sk_dbg();
+
 hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const void *recs, int k, u64 *cursor, u64 *seg_off,
                            u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
 {
@@ -978,7 +984,7 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const v
         n_cu = prop.multiProcessorCount;
     const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
     hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, n_list, reinterpret_cast<const ull2_t *>(recs),
-                       k, reinterpret_cast<unsigned long long *>(cursor), seg_off, seg_cnt, out_keys, out_counts);
+                       k, reinterpret_cast<unsigned long long *>(cursor), seg_off, seg_cnt, out_keys, out_counts, sk_dbg());
     return hipGetLastError();
 }
 
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__rest
     if (i >= n_fin)
         return;
     const u32 km = fin[i].child_base;
-    const bool small = km <= cap && fin[i].len <= (u32)SKC_MAXREC;
+    const bool small = km <= cap && fin[i].len <= (u32)SKC_MAXREC && fin[i].chunk_base <= (u32)SKC_MAXQ;
     f_small[i] = km > 0 && small ? 1u : 0u;
     f_over[i] = km > 0 && !small ? 1u : 0u;
     k_over[i] = km > 0 && !small ? km : 0u;
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__rest
         return;
     const Node nd = fin[i];
     const u32 km = nd.child_base;
-    const bool small = km <= cap && nd.len <= (u32)SKC_MAXREC;
+    const bool small = km <= cap && nd.len <= (u32)SKC_MAXREC && nd.chunk_base <= (u32)SKC_MAXQ;
     if (km > 0 && small)
         list_small[p_small[i]] = i;
     if (km > 0 && !small) {

@@ -288,6 +288,9 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * dnagpu_buffer_alloc -- is first filled with 0xFF bytes on the context's stream, so a kernel that reads a
  * work buffer before writing it sees garbage in every run, not only in a warm context. */
 #define DNAGPU_DEBUG_POISON_POOL 1u
+/* DNAGPU_DEBUG_FORCE_SUPERKMER: dnagpu_count_kmers_unordered takes the super-k-mer engine for every k it supports
+ * (23..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
+#define DNAGPU_DEBUG_FORCE_SUPERKMER 2u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

@@ -612,30 +612,42 @@ def check_hist_unordered(hist, ok, oc, what):
 
 
 @pytest.mark.parametrize("n,k,first", [(5_000_011, 31, 0), (4_500_000, 32, 0), (6_000_000, 27, 7), (5_000_000, 23, 33),
-                                       (9_000_000, 31, 12345), (17_000_029, 31, 0), (40_000_000, 29, 1)])
-def test_count_unordered_superkmers(ctx, n, k, first):
+                                       (9_000_000, 31, 12345), (17_000_029, 31, 0), (40_000_000, 29, 1),
+                                       (3_000_000, 24, 0), (3_000_000, 25, 5), (3_000_000, 26, 0), (3_000_000, 28, 31),
+                                       (3_000_000, 30, 0), (70_000, 31, 3), (1_000, 32, 0)])
+def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     """dnagpu_count_kmers_unordered on sequences long enough for super-k-mer partitioning: the groups are the
     oracle's (sorted on the host for the comparison); a window that does not start on a word boundary"""
     words = orc.synth_words(0x5EED + n, n)
     d = ctx.upload(words, n)
     keys = orc.generate_kmers(words, n, k, faithful=False)[first:]
     ok, oc = orc.count_keys(keys)
-    h = ctx.count_kmers_unordered(d, k, first=first)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)         # also for the k below 29, where the tree is the faster engine
+    try:
+        h = ctx.count_kmers_unordered(d, k, first=first)
+    finally:
+        ctx.set_debug(0)
     assert not h.is_sorted
     assert h.total == len(keys)
     check_hist_unordered(h, ok, oc, f"unordered n={n} k={k} first={first}")
     h.free()
+    if k >= 29 and len(keys) >= (1 << 22):           # the default choice of engine
+        h = ctx.count_kmers_unordered(d, k, first=first)
+        assert not h.is_sorted
+        assert h.summary() == orc.hist_summary(ok, oc)
+        h.free()
     # short sequences and short k-mers take the ordinary engine behind the same entry point
-    h = ctx.count_kmers_unordered(d, 12, first=first, count=1_000_000)
+    cnt12 = min(1_000_000, n - 12 + 1 - first)
+    h = ctx.count_kmers_unordered(d, 12, first=first, count=cnt12)
     assert h.is_sorted
-    ok, oc = orc.count_keys(orc.generate_kmers(words, n, 12, faithful=False)[first:first + 1_000_000])
+    ok, oc = orc.count_keys(orc.generate_kmers(words, n, 12, faithful=False)[first:first + cnt12])
     check_hist(h, ok, oc, "unordered entry, short k")
     h.free()
     d.free()
 
 
 @pytest.mark.parametrize("kind", ["motif1000", "motif37", "polyA", "half-polyA", "AT"])
-def test_count_unordered_repeats(ctx, kind):
+def test_count_unordered_repeats(ctx, pkg, kind):
     """repeat-rich and low-complexity inputs through the unordered entry: heavy buckets are split further by the
     ordinary levels; a bucket too heavy for one workgroup sends the whole count to the ordinary engine"""
     n, k = 6_000_000, 31
@@ -653,6 +665,19 @@ def test_count_unordered_repeats(ctx, kind):
     h = ctx.count_kmers_unordered(d, k)
     check_hist_unordered(h, ok, oc, f"unordered {kind}")
     h.free()
+    # a short sequence (few, small buckets) of the same kind, the engine forced
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    try:
+        m = 300_000
+        ok, oc = orc.count_kmers(words, m, k)
+        ds = ctx.upload(words[: (m + 31) // 32].copy() & np.uint64(0xFFFFFFFFFFFFFFFF), m) if m % 32 == 0 else None
+        if ds is not None:
+            h = ctx.count_kmers_unordered(ds, k)
+            check_hist_unordered(h, ok, oc, f"unordered {kind}, short")
+            h.free()
+            ds.free()
+    finally:
+        ctx.set_debug(0)
     d.free()
 
 
@@ -719,7 +744,8 @@ def test_partition_by_owner(ctx, n_owners):
             assert hi - lo == len(want), f"owner {o}: {hi - lo} keys, oracle {len(want)}"
             if hi > lo:
                 import importlib
-                sh = importlib.import_module(load_package().__name__ + ".sharded")
+                # (shard_math, not sharded: importing torch here would put a second ROCm runtime into this process)
+                sh = importlib.import_module(load_package().__name__ + ".shard_math")
                 kmin, kmax = sh.owner_key_range(k, o, n_owners)
                 assert int(want[0]) >= kmin and int(want[-1]) <= kmax
                 if o % 2:     # both entry points
@@ -784,8 +810,9 @@ def test_count_multi_one_process(pkg, n_ranks):
             m.dna_free(d)
 
 
-def test_count_multi_rccl_one_rank(pkg):
+def test_count_multi_rccl_one_rank(pkg, ctx):
     """the RCCL transport (librccl.so loaded on demand, ncclCommInitAll) with the one device a test box has"""
+    ctx.trim()          # the module's context has pooled the full-size configs' work buffers: RCCL allocates on its own
     n, k, seed = 1_000_003, 31, 0xD2A0002
     words = orc.synth_words(seed, n)
     with pkg.Multi([0], pkg.MULTI_RCCL) as m:

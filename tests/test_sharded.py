@@ -11,7 +11,16 @@ import pytest
 from __graft_entry__ import ROOT, load_package
 
 
+def free_port():
+    """a port nobody listens on right now (two test sessions on one box must not share a rendezvous port)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather", backend="gloo"):
+    port = free_port()                      # (the callers' fixed numbers are kept only as labels)
     out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}_{backend}.json"
     procs = []
     for r in range(world):
@@ -26,7 +35,7 @@ def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather", backend=
 
 def test_shard_ranges_cover_exactly_once():
     pkg = load_package()
-    sh = importlib.import_module(pkg.__name__ + ".sharded")
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
     for n, k, w in [(1000, 31, 2), (1000, 31, 8), (64, 32, 3), (31, 31, 4), (30, 31, 2), (3_000_000_000, 31, 8)]:
         r = sh.shard_ranges(n, k, w)
         n_kmers = max(n - k + 1, 0)
@@ -41,7 +50,7 @@ def test_shard_ranges_cover_exactly_once():
 
 def test_word_chunks_cover_the_sequence():
     pkg = load_package()
-    sh = importlib.import_module(pkg.__name__ + ".sharded")
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
     for n, w in [(1000, 2), (1000, 8), (64, 3), (31, 4), (3_000_000_000, 8), (33, 5)]:
         per, chunks = sh.word_chunks(n, w)
         assert sum(c[1] for c in chunks) == n
