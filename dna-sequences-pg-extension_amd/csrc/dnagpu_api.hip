@@ -1316,11 +1316,17 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     std::vector<Node> kids(l0.n_next);
     HIP_TRY(hipMemcpyAsync(kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    u64 n_recs = 0;
-    for (const Node &c : kids)
+    u64 n_recs = 0, max_coarse = 0;
+    for (const Node &c : kids) {
         n_recs += c.len;
+        max_coarse = std::max<u64>(max_coarse, c.len);
+    }
     if (n_recs > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
+    // first skew check, 3 ms into the count: uniform sequence fills the coarse buckets within a fraction of a per cent
+    // of each other (tens of millions of records each); a bucket 10 % over the mean means heavy minimizers (repeats)
+    if (n >= ((u64)1 << 26) && max_coarse * c0n > n_recs + n_recs / 10)
+        return DNAGPU_SK_SKEWED;
     void *rec0 = nullptr, *rec1 = nullptr;
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec0));
     ps.ptrs.push_back(rec0);
