@@ -1277,9 +1277,18 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
 
 // The three partition levels.  On success: *recs = the record buffer holding the final buckets, *fin / *n_fin =
 // their nodes (start / len in records, child_base = k-mers), all pool memory of `ps`.
+// Heavy mid buckets (more than SK_MID_LIMIT k-mers: the minimizers of repeats) are taken out of the record path: their
+// nodes come back in *heavy (device copies, start / len in records of *heavy_recs), their k-mer counts in heavy_kc.
+struct SkHeavy {
+    Node *nodes = nullptr;      // device, n entries
+    void *recs = nullptr;       // the record buffer they live in
+    std::vector<u32> kc;        // k-mers of each
+    u64 total = 0;
+};
 static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, void **recs,
-                        Node **fin, u32 *n_fin)
+                        Node **fin, u32 *n_fin, SkHeavy *heavy)
 {
+
     hipStream_t st = ctx->stream;
     // geometry: final buckets of ~SK_LEAF_MEAN k-mers = 16 per mid bucket; mid buckets = C0 coarse x 2^b1
     const u64 n_final = std::max<u64>(n / SK_LEAF_MEAN, 16);
@@ -1291,6 +1300,8 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     int r0bits = 1;
     while ((1u << r0bits) < c0n)
         r0bits++;
+    // (the forced engine of the tests calls a bucket heavy at three times the mean, so that short sequences take that path too)
+    const u64 mid_limit = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) ? 3 * (n / ((u64)c0n << b1) + 1) : SK_MID_LIMIT;
 
     // ---- level 0: the packed sequence -> records in c0n coarse buckets
     Node root;
@@ -1316,17 +1327,11 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     std::vector<Node> kids(l0.n_next);
     HIP_TRY(hipMemcpyAsync(kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    u64 n_recs = 0, max_coarse = 0;
-    for (const Node &c : kids) {
+    u64 n_recs = 0;
+    for (const Node &c : kids)
         n_recs += c.len;
-        max_coarse = std::max<u64>(max_coarse, c.len);
-    }
     if (n_recs > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
-    // first skew check, 3 ms into the count: uniform sequence fills the coarse buckets within a fraction of a per cent
-    // of each other (tens of millions of records each); a bucket 10 % over the mean means heavy minimizers (repeats)
-    if (n >= ((u64)1 << 26) && max_coarse * c0n > n_recs + n_recs / 10)
-        return DNAGPU_SK_SKEWED;
     void *rec0 = nullptr, *rec1 = nullptr;
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec0));
     ps.ptrs.push_back(rec0);
@@ -1361,20 +1366,48 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
         set_err("super-k-mer partition lost rows: %llu of %llu", (unsigned long long)run, (unsigned long long)n);
         return DNAGPU_ERR_INTERNAL;
     }
-    if (heaviest > SK_MID_LIMIT)
-        return DNAGPU_SK_SKEWED;
+    std::vector<u32> heavy_idx;
+    if (heaviest > mid_limit) {
+        for (u32 i = 0; i < l1.n_next; i++)
+            if (kc[i] > mid_limit) {
+                heavy_idx.push_back(i);
+                heavy->total += kc[i];
+            }
+        // The heavy buckets are expanded by one workgroup each: fine for the few per cent of a genome that sit in long
+        // repeats; a sequence that is mostly repeats (poly-A, a motif tiled over half of it) is cheaper through the
+        // tree from scratch.
+        if (heavy->total * 16 > n || heavy_idx.size() > 4096)
+            return DNAGPU_SK_SKEWED;
+    }
 
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
     ps.ptrs.push_back(rec1);
     prof_mark(ctx, "sk_scatter1");
     HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
 
+    if (!heavy_idx.empty()) {
+        // the heavy buckets leave the record path here: copies of their nodes for the expansion, empty nodes in the list
+        std::vector<Node> mids(l1.n_next), hv;
+        HIP_TRY(hipMemcpyAsync(mids.data(), l1.next, (size_t)l1.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (u32 i : heavy_idx) {
+            hv.push_back(mids[i]);
+            heavy->kc.push_back(kc[i]);
+            mids[i].len = 0;
+        }
+        RC_TRY(ps.alloc(hv.size(), &heavy->nodes));
+        HIP_TRY(hipMemcpyAsync(heavy->nodes, hv.data(), hv.size() * sizeof(Node), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(l1.next, mids.data(), (size_t)l1.n_next * sizeof(Node), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));       // (host vectors)
+        heavy->recs = rec1;
+    }
     // ---- level 2: every mid bucket regrouped by d2 (rec1 -> rec0): 16 final buckets each
     Node *fn = nullptr;
     RC_TRY(ps.alloc((size_t)l1.n_next * 16, &fn));
     prof_mark(ctx, "sk_regroup");
     HIP_TRY(launch_sk_regroup(l1.next, l1.n_next, rec1, rec0, fn, st));
-    ps.free_now(rec1);
+    if (heavy_idx.empty())
+        ps.free_now(rec1);
     *recs = rec0;
     *fin = fn;
     *n_fin = l1.n_next * 16;
@@ -1390,7 +1423,9 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     void *recs = nullptr;
     Node *fin = nullptr;
     u32 n_fin = 0;
-    RC_TRY(sk_partition(ctx, ps, dna, first, n, k, &recs, &fin, &n_fin));
+    SkHeavy heavy;
+    RC_TRY(sk_partition(ctx, ps, dna, first, n, k, &recs, &fin, &n_fin, &heavy));
+    const u32 n_heavy = (u32)heavy.kc.size();
     prof_mark(ctx, "sk_select");
     const u32 cap = (u32)sk_count_cap();
     u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *scan_tmp = nullptr, *totals = nullptr, *list_small = nullptr;
@@ -1426,15 +1461,34 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     memset(&tr, 0, sizeof tr);
     u64 *seg_off = nullptr;
     u32 *seg_cnt = nullptr;
-    if (n_over > 0) {
-        // oversize buckets (heavy repeats, or the tail of the size distribution): keys, then the ordinary levels
+    if (n_over + n_heavy > 0) {
+        // oversize final buckets (the tail of the size distribution, moderate repeats) and heavy mid buckets (the
+        // minimizers of long repeats): keys, then the ordinary levels with their skew paths
+        const u64 tree_keys = over_keys + heavy.total;
+        if (tree_keys > 0xFFFFFFFFull)
+            return DNAGPU_ERR_TOO_LARGE;
         u64 *kbuf = nullptr;
         Node *knodes = nullptr;
-        RC_TRY(ps.alloc((size_t)over_keys, &kbuf));
-        RC_TRY(ps.alloc((size_t)n_over * 16, &knodes));
+        RC_TRY(ps.alloc((size_t)tree_keys, &kbuf));
+        RC_TRY(ps.alloc((size_t)(n_over + n_heavy) * 16, &knodes));
         prof_mark(ctx, "sk_expand");
         HIP_TRY(launch_sk_expand(over_nodes, n_over, recs, over_kbase, k, kbuf, knodes, st));
-        RC_TRY(run_tree(ctx, ps, nullptr, 0, over_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes, n_over * 16, 2));
+        if (n_heavy > 0) {
+            std::vector<u32> hkb(n_heavy);
+            u64 run = over_keys;
+            for (u32 i = 0; i < n_heavy; i++) {
+                hkb[i] = (u32)run;
+                run += heavy.kc[i];
+            }
+            u32 *heavy_kbase = nullptr;
+            RC_TRY(ps.alloc((size_t)n_heavy, &heavy_kbase));
+            HIP_TRY(hipMemcpyAsync(heavy_kbase, hkb.data(), (size_t)n_heavy * sizeof(u32), hipMemcpyHostToDevice, st));
+            HIP_TRY(launch_sk_expand(heavy.nodes, n_heavy, heavy.recs, heavy_kbase, k, kbuf, knodes + (size_t)n_over * 16, st,
+                                     true));
+            HIP_TRY(hipStreamSynchronize(st));   // (hkb is a host vector)
+        }
+        RC_TRY(run_tree(ctx, ps, nullptr, 0, tree_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes,
+                        (n_over + n_heavy) * 16, 2));
     }
     const u32 n_segs = n_fin + tr.n_nodes;
     RC_TRY(ps.alloc((size_t)n_segs, &seg_off));

@@ -156,8 +156,9 @@ hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks,
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
                               const u32 *tot, hipStream_t s);
 // mids[i] (start / len in records) -> keys at key_base[i] ..., out_nodes[16 i .. 16 i + 15]
+// heavy: one workgroup of eight waves per bucket (buckets of millions of k-mers) instead of one wave
 hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
-                            Node *out_nodes, hipStream_t s);
+                            Node *out_nodes, hipStream_t s, bool heavy = false);
 
 // every mid bucket's records regrouped by d2 from src into the same range of dst; out_nodes[16 i + j] = final bucket:
 // start / len in records, child_base = its k-mers

@@ -503,23 +503,36 @@ __device__ __forceinline__ u32 row16_excl_scan(u32 x)
     return (u32)v - x;
 }
 
-__global__ __launch_bounds__(SKX_NT) void sk_expand_kernel(const Node *__restrict__ mids, u32 n_mids,
+// WPB = waves per bucket: 1 (a workgroup's waves take a bucket each) or SKX_HEAVY_WAVES (one workgroup per HEAVY bucket --
+// millions of k-mers of a repeat's minimizer --, every wave a slice of its records, the slices' places inside the 16
+// groups settled with one barrier after sweep A).
+constexpr int SKX_HEAVY_WAVES = 8;
+template <int WPB>
+__global__ __launch_bounds__(64 * (WPB == 1 ? SKX_WAVES : WPB)) void sk_expand_kernel(const Node *__restrict__ mids, u32 n_mids,
                                                            const ull2_t *__restrict__ recs,
                                                            const u32 *__restrict__ key_base, int k, u32 lmax,
                                                            u64 *__restrict__ keys, Node *__restrict__ out_nodes, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    __shared__ u32 wcnt[WPB == 1 ? 1 : WPB][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 i = blockIdx.x * SKX_WAVES + (u32)wave;
+    const u32 i = WPB == 1 ? blockIdx.x * SKX_WAVES + (u32)wave : blockIdx.x;
     if (i >= n_mids)
-        return;                                   // (whole waves leave: nothing below synchronises across waves)
+        return;                                   // (WPB == 1: whole waves leave, nothing below synchronises across waves)
     const u32 stage_keys = 64u * lmax;
     unsigned char *mine = sk_smem + (size_t)wave * ((size_t)stage_keys * 8 + 5 * 16 * 4);
     u64 *stage = reinterpret_cast<u64 *>(mine);
     u32 *sc = reinterpret_cast<u32 *>(mine + (size_t)stage_keys * 8);   // keys per d2 (sweep A: of the bucket; B: of the batch)
     u32 *scur = sc + 16, *nbase = sc + 32, *done = sc + 48;
-    const Node nd = mids[i];
+    Node nd = mids[i];
     const u64 kmask = kmer_mask(k);
+    if (WPB > 1) {                                // this wave's slice of the bucket's records (whole batches of 64)
+        const u32 per = ((nd.len + WPB - 1) / WPB + 63u) & ~63u;
+        const u32 s0 = (u32)wave * per < nd.len ? (u32)wave * per : nd.len;
+        const u32 s1 = s0 + per < nd.len ? s0 + per : nd.len;
+        nd.start += s0;
+        nd.len = s1 - s0;
+    }
     const ull2_t *src = recs + (u64)nd.start;
 
     if (lane < 16) {
@@ -542,7 +555,35 @@ __global__ __launch_bounds__(SKX_NT) void sk_expand_kernel(const Node *__restric
     }
     sk_wave_fence();
     const u32 kb = key_base[i];
-    {
+    if (WPB > 1) {
+        // the slices' k-mers per d2 -> the bucket's totals (the 16 nodes) and every slice's place inside each node
+        if (lane < 16)
+            wcnt[wave][lane] = sc[lane];
+        __syncthreads();
+        u32 tot = 0, mine_before = 0;
+        if (lane < 16)
+            for (int w = 0; w < WPB; w++) {
+                const u32 t = wcnt[w][lane];
+                mine_before += w < wave ? t : 0u;
+                tot += t;
+            }
+        const u32 ex = row16_excl_scan(tot);
+        if (lane < 16) {
+            nbase[lane] = ex;
+            done[lane] = mine_before;
+            if (wave == 0) {
+                Node o;
+                o.start = kb + ex;
+                o.len = tot;
+                o.meta = (u32)(2 * k);
+                o.split = 0;
+                o.prefix = 0;
+                o.child_base = 0;
+                o.chunk_base = 0;
+                out_nodes[(u64)i * 16 + lane] = o;
+            }
+        }
+    } else {
         const u32 v = lane < 16 ? sc[lane] : 0u;
         const u32 ex = row16_excl_scan(v);
         if (lane < 16) {
@@ -1056,7 +1097,6 @@ static int sk_dbg()
 
 // ------------------------------------------------------------------------------------------------
 // launchers
-static bool g_sk_attr_done = false;               // (set per call: the attribute is per device and cheap to set)
 template <int W>
 static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk *chunks, const u64 *words, u64 n_words,
                          u64 first, int k, u32 lmax, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs)
@@ -1113,23 +1153,29 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
 }
 
 hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
-                            Node *out_nodes, hipStream_t s)
+                            Node *out_nodes, hipStream_t s, bool heavy)
 {
     if (n_mids == 0)
         return hipSuccess;
     u32 lmax = (u32)(54 - k + 1);
     if (lmax > 32)
         lmax = 32;
-    const size_t smem = (size_t)SKX_WAVES * ((size_t)64 * lmax * 8 + 5 * 16 * 4);
-    if (!g_sk_attr_done) {        // (the same value for every k: the largest stage)
-        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)((size_t)SKX_WAVES * ((size_t)64 * 32 * 8 + 5 * 16 * 4)));
-        if (ae != hipSuccess)
-            return ae;
-    }
-    hipLaunchKernelGGL(sk_expand_kernel, dim3((n_mids + SKX_WAVES - 1) / SKX_WAVES), dim3(SKX_NT), smem, s, mids, n_mids,
-                       reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax, keys, out_nodes, sk_dbg());
+    const size_t per_wave = (size_t)64 * lmax * 8 + 5 * 16 * 4, per_wave_max = (size_t)64 * 32 * 8 + 5 * 16 * 4;
+    // (set per call: the attribute is per device and cheap to set)
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SKX_WAVES * per_wave_max));
+    if (ae == hipSuccess)
+        ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel<SKX_HEAVY_WAVES>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SKX_HEAVY_WAVES * per_wave_max));
+    if (ae != hipSuccess)
+        return ae;
+    if (heavy)
+        hipLaunchKernelGGL(sk_expand_kernel<SKX_HEAVY_WAVES>, dim3(n_mids), dim3(64 * SKX_HEAVY_WAVES),
+                           SKX_HEAVY_WAVES * per_wave, s, mids, n_mids, reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax,
+                           keys, out_nodes, sk_dbg());
+    else
+        hipLaunchKernelGGL(sk_expand_kernel<1>, dim3((n_mids + SKX_WAVES - 1) / SKX_WAVES), dim3(SKX_NT), SKX_WAVES * per_wave,
+                           s, mids, n_mids, reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax, keys, out_nodes, sk_dbg());
     return hipGetLastError();
 }
 

@@ -646,7 +646,8 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     d.free()
 
 
-@pytest.mark.parametrize("kind", ["motif1000", "motif37", "polyA", "half-polyA", "AT"])
+@pytest.mark.parametrize("kind", ["motif1000", "motif37", "motif100000", "polyA", "half-polyA", "quarter-polyA", "AT",
+                                  "small-polyA", "small-AT"])
 def test_count_unordered_repeats(ctx, pkg, kind):
     """repeat-rich and low-complexity inputs through the unordered entry: heavy buckets are split further by the
     ordinary levels; a bucket too heavy for one workgroup sends the whole count to the ordinary engine"""
@@ -657,6 +658,15 @@ def test_count_unordered_repeats(ctx, pkg, kind):
         words = np.zeros((n + 31) // 32, dtype=np.uint64)
     elif kind == "AT":
         words, _ = orc.dna_encode("AT" * (n // 2))
+    elif kind in ("small-polyA", "small-AT"):
+        # 3 % of the sequence is one repeat: its bucket is heavy (forced engine: > 3 x the mean) but small enough to
+        # leave the record path alone, through the eight-wave expansion, while the rest stays on it
+        words = orc.synth_words(94, n)
+        rep = 0 if kind == "small-polyA" else int(orc.dna_encode("AT" * 16)[0][0])
+        words[1000:1000 + 200_000 // 32] = rep
+    elif kind == "quarter-polyA":
+        words = orc.synth_words(93, n)
+        words[: len(words) // 4] = 0
     else:
         words = orc.synth_words(92, n)
         words[: len(words) // 2] = 0
@@ -665,6 +675,15 @@ def test_count_unordered_repeats(ctx, pkg, kind):
     h = ctx.count_kmers_unordered(d, k)
     check_hist_unordered(h, ok, oc, f"unordered {kind}")
     h.free()
+    # the engine forced: its "heavy bucket" limit is then 16 K k-mers, so the repeats' buckets leave the record path
+    # through the eight-wave expansion (what buckets of millions of k-mers do at full size)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    try:
+        h = ctx.count_kmers_unordered(d, k)
+        check_hist_unordered(h, ok, oc, f"unordered {kind}, heavy buckets split off")
+        h.free()
+    finally:
+        ctx.set_debug(0)
     # a short sequence (few, small buckets) of the same kind, the engine forced
     ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
     try:
