@@ -785,6 +785,16 @@ hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void
     return hipGetLastError();
 }
 
+// {sum of vals[0 .. wave), sum of all n <= 16 values} from one LDS read per lane and a 16-lane DPP scan (instead of a
+// loop of n LDS reads in every thread)
+__device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wave, int lane, u32 &before, u32 &total)
+{
+    const u32 v = lane < n ? vals[lane] : 0u;
+    const u32 ex = row16_excl_scan(v);             // lanes 0..15
+    total = (u32)__builtin_amdgcn_readlane((int)(ex + v), 15);
+    before = (u32)__builtin_amdgcn_readlane((int)ex, wave < 16 ? wave : 15);
+}
+
 // ------------------------------------------------------------------------------------------------
 // sk_count: the leaves of the super-k-mer engine.  A final bucket of at most sk_count_cap() k-mers in at most
 // SKC_MAXREC records is counted straight from its records in the workgroup's LDS hash table (linear probing, 64-bit
@@ -795,6 +805,9 @@ hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void
 //   gives every quad a thread, and every record writes its quads' owner entries itself -- no search.  Records and
 //   owner table live in LDS, so that nothing between two barriers waits for global memory: the next bucket's records
 //   are requested a whole bucket ahead, the output range (one atomic add on the global cursor) one bucket behind.
+//   Measured and dropped here: the quad's four first probes issued back to back before any result is examined (18.9 vs
+//   17.8 ms at 3 Gbase: more registers live, a 16-byte spill); eight k-mers per thread at 512 threads (24.7 ms: half
+//   the waves); a binary search over the prefix instead of the owner table (19.6 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
 constexpr int SKC_SLOTS = 106 * 64;              // 6784 slots (load 0.49 at 3300 keys): with the tables below 79.9 KiB, two workgroups per CU
@@ -893,12 +906,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         u32 n_quads = 0;
         {
             u32 qb = 0;
-#pragma unroll
-            for (int w = 0; w < RWAVES; w++) {
-                const u32 t = wq[w];
-                qb += w < wave ? t : 0u;
-                n_quads += t;
-            }
+            sk_wave_prefix16(wq, RWAVES, wave, lane, qb, n_quads);
             if (tid < SKC_MAXREC) {
                 const u32 q0 = qb + qinc - nq;
                 for (u32 q = 0; q < nq; q++)
@@ -970,12 +978,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             emit_prev(par ^ 1);
         // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
         u32 before = 0, D = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            const u32 t = wclaim[par][w];
-            before += w < wave ? t : 0u;
-            D += t;
-        }
+        sk_wave_prefix16(wclaim[par], WAVES, wave, lane, before, D);
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
             pk[q] = ck[q];
