@@ -1237,7 +1237,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 // instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
 constexpr u64 SK_LEAF_MEAN = 2900;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
-constexpr u64 SK_MID_LIMIT = (u64)1 << 21;       // most k-mers one mid bucket may hold (planned: 16 x SK_LEAF_MEAN)
+constexpr u64 SK_MID_LIMIT = 8 * 16 * SK_LEAF_MEAN;  // a mid bucket (planned: 16 x SK_LEAF_MEAN k-mers) eight times over is "heavy"
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;
@@ -1280,10 +1280,10 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
 // Heavy mid buckets (more than SK_MID_LIMIT k-mers: the minimizers of repeats) are taken out of the record path: their
 // nodes come back in *heavy (device copies, start / len in records of *heavy_recs), their k-mer counts in heavy_kc.
 struct SkHeavy {
-    Node *nodes = nullptr;      // device, n entries
+    Node *nodes = nullptr;      // device, n entries: start / len in records, child_base = k-mers
+    u32 n = 0;
     void *recs = nullptr;       // the record buffer they live in
-    std::vector<u32> kc;        // k-mers of each
-    u64 total = 0;
+    u64 total = 0;              // k-mers of all
 };
 static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, void **recs,
                         Node **fin, u32 *n_fin, SkHeavy *heavy)
@@ -1373,10 +1373,9 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
                 heavy_idx.push_back(i);
                 heavy->total += kc[i];
             }
-        // The heavy buckets are expanded by one workgroup each: fine for the few per cent of a genome that sit in long
-        // repeats; a sequence that is mostly repeats (poly-A, a motif tiled over half of it) is cheaper through the
-        // tree from scratch.
-        if (heavy->total * 16 > n || heavy_idx.size() > 4096)
+        // a sequence that is mostly repeats (poly-A, satellites over more than half of it) is cheaper through the tree
+        // from scratch
+        if (heavy->total * 2 > n || heavy_idx.size() > 4096)
             return DNAGPU_SK_SKEWED;
     }
 
@@ -1387,18 +1386,14 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
 
     if (!heavy_idx.empty()) {
         // the heavy buckets leave the record path here: copies of their nodes for the expansion, empty nodes in the list
-        std::vector<Node> mids(l1.n_next), hv;
-        HIP_TRY(hipMemcpyAsync(mids.data(), l1.next, (size_t)l1.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (u32 i : heavy_idx) {
-            hv.push_back(mids[i]);
-            heavy->kc.push_back(kc[i]);
-            mids[i].len = 0;
-        }
-        RC_TRY(ps.alloc(hv.size(), &heavy->nodes));
-        HIP_TRY(hipMemcpyAsync(heavy->nodes, hv.data(), hv.size() * sizeof(Node), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(l1.next, mids.data(), (size_t)l1.n_next * sizeof(Node), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));       // (host vectors)
+        u32 *d_idx = nullptr;
+        const u32 nh = (u32)heavy_idx.size();
+        RC_TRY(ps.alloc((size_t)nh, &d_idx));
+        RC_TRY(ps.alloc((size_t)nh, &heavy->nodes));
+        HIP_TRY(hipMemcpyAsync(d_idx, heavy_idx.data(), (size_t)nh * sizeof(u32), hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_sk_take_heavy(l1.next, d_idx, nh, kcount, heavy->nodes, st));
+        HIP_TRY(hipStreamSynchronize(st));       // (heavy_idx is a host vector)
+        heavy->n = nh;
         heavy->recs = rec1;
     }
     // ---- level 2: every mid bucket regrouped by d2 (rec1 -> rec0): 16 final buckets each
@@ -1425,7 +1420,7 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     u32 n_fin = 0;
     SkHeavy heavy;
     RC_TRY(sk_partition(ctx, ps, dna, first, n, k, &recs, &fin, &n_fin, &heavy));
-    const u32 n_heavy = (u32)heavy.kc.size();
+    const u32 n_heavy = heavy.n;
     prof_mark(ctx, "sk_select");
     const u32 cap = (u32)sk_count_cap();
     u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *scan_tmp = nullptr, *totals = nullptr, *list_small = nullptr;
@@ -1453,42 +1448,58 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     // output arrays and the segment directory: final buckets first, the nodes of the oversize buckets' tree behind them
     u64 *cursor = nullptr, *ok = nullptr;
     u32 *oc = nullptr;
-    RC_TRY(ps.alloc(1, &cursor));
+    RC_TRY(ps.alloc(2, &cursor));                // [0] groups written so far; [1] buckets whose expansion disagrees with the partition's count
     RC_TRY(ps.alloc((size_t)n, &ok));
     RC_TRY(ps.alloc((size_t)n, &oc));
-    HIP_TRY(hipMemsetAsync(cursor, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(cursor, 0, 16, st));
     TreeResult tr;
     memset(&tr, 0, sizeof tr);
     u64 *seg_off = nullptr;
     u32 *seg_cnt = nullptr;
     if (n_over + n_heavy > 0) {
         // oversize final buckets (the tail of the size distribution, moderate repeats) and heavy mid buckets (the
-        // minimizers of long repeats): keys, then the ordinary levels with their skew paths
+        // minimizers of long repeats): keys, then the ordinary levels with their skew paths.  Every such bucket becomes
+        // one key node; its records are expanded in slices by many waves at once.
         const u64 tree_keys = over_keys + heavy.total;
         if (tree_keys > 0xFFFFFFFFull)
             return DNAGPU_ERR_TOO_LARGE;
+        const u32 n_tree = n_over + n_heavy;
         u64 *kbuf = nullptr;
         Node *knodes = nullptr;
         RC_TRY(ps.alloc((size_t)tree_keys, &kbuf));
-        RC_TRY(ps.alloc((size_t)(n_over + n_heavy) * 16, &knodes));
+        RC_TRY(ps.alloc((size_t)n_tree, &knodes));
         prof_mark(ctx, "sk_expand");
-        HIP_TRY(launch_sk_expand(over_nodes, n_over, recs, over_kbase, k, kbuf, knodes, st));
-        if (n_heavy > 0) {
-            std::vector<u32> hkb(n_heavy);
-            u64 run = over_keys;
-            for (u32 i = 0; i < n_heavy; i++) {
-                hkb[i] = (u32)run;
-                run += heavy.kc[i];
-            }
-            u32 *heavy_kbase = nullptr;
-            RC_TRY(ps.alloc((size_t)n_heavy, &heavy_kbase));
-            HIP_TRY(hipMemcpyAsync(heavy_kbase, hkb.data(), (size_t)n_heavy * sizeof(u32), hipMemcpyHostToDevice, st));
-            HIP_TRY(launch_sk_expand(heavy.nodes, n_heavy, heavy.recs, heavy_kbase, k, kbuf, knodes + (size_t)n_over * 16, st,
-                                     true));
-            HIP_TRY(hipStreamSynchronize(st));   // (hkb is a host vector)
+        // the final buckets live in `recs`, the heavy mid buckets in heavy.recs -> two slice lists; the key ranges: the
+        // oversize final buckets in list order, the heavy buckets behind them
+        for (int part = 0; part < 2; part++) {
+            const u32 nb = part == 0 ? n_over : n_heavy;
+            if (nb == 0)
+                continue;
+            const void *rbuf = part == 0 ? recs : heavy.recs;
+            const Node *bk = part == 0 ? over_nodes : heavy.nodes;     // (start / len in records, child_base = k-mers)
+            u32 *sfirst = nullptr, *stmp = nullptr, *stot = nullptr;
+            RC_TRY(ps.alloc((size_t)nb, &sfirst));
+            RC_TRY(ps.alloc((size_t)scan_tmp_words(nb), &stmp));
+            RC_TRY(ps.alloc(2, &stot));
+            HIP_TRY(launch_sk_slice_count(bk, nb, sfirst, st));
+            HIP_TRY(launch_scan_u32(sfirst, sfirst, nb, stmp, stot, st));
+            u32 n_slices = 0;
+            HIP_TRY(hipMemcpyAsync(&n_slices, stot, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            u32 *d_r0 = nullptr, *d_nr = nullptr, *d_ko = nullptr, *ktmp = nullptr;
+            RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &d_r0));
+            RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &d_nr));
+            RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &d_ko));
+            RC_TRY(ps.alloc((size_t)scan_tmp_words(std::max<u32>(n_slices, 1)), &ktmp));
+            HIP_TRY(launch_sk_slice_fill(bk, nb, sfirst, d_r0, d_nr, st));
+            HIP_TRY(launch_sk_slice_kmers(rbuf, d_r0, d_nr, n_slices, d_ko, st));
+            HIP_TRY(launch_scan_u32(d_ko, d_ko, n_slices, ktmp, stot + 1, st));
+            const u32 key_base = part == 0 ? 0u : (u32)over_keys;
+            HIP_TRY(launch_sk_slice_nodes(bk, nb, sfirst, d_ko, n_slices, stot + 1, key_base, k, true, knodes + (part == 0 ? 0 : n_over),
+                                          cursor + 1, st));
+            HIP_TRY(launch_sk_expand_flat(rbuf, d_r0, d_nr, d_ko, key_base, n_slices, k, kbuf, st));
         }
-        RC_TRY(run_tree(ctx, ps, nullptr, 0, tree_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes,
-                        (n_over + n_heavy) * 16, 2));
+        RC_TRY(run_tree(ctx, ps, nullptr, 0, tree_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes, n_tree, 2));
     }
     const u32 n_segs = n_fin + tr.n_nodes;
     RC_TRY(ps.alloc((size_t)n_segs, &seg_off));
@@ -1507,9 +1518,15 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     prof_mark(ctx, "sk_count");
     HIP_TRY(launch_sk_count(fin, list_small, n_small, recs, k, cursor, seg_off, seg_cnt, ok, oc, st));
     prof_mark(ctx, "end");
-    u64 total_groups = 0;
-    HIP_TRY(hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, st));
+    u64 fin_ctr[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(fin_ctr, cursor, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const u64 total_groups = fin_ctr[0];
+    if (fin_ctr[1] != 0) {
+        set_err("super-k-mer count: %llu buckets whose records expand to a different number of k-mers than the partition counted",
+                (unsigned long long)fin_ctr[1]);
+        return DNAGPU_ERR_INTERNAL;
+    }
     if (total_groups > n) {
         set_err("super-k-mer count: %llu groups for %llu rows", (unsigned long long)total_groups, (unsigned long long)n);
         return DNAGPU_ERR_INTERNAL;

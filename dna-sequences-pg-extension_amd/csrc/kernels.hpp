@@ -155,11 +155,20 @@ hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks,
                            hipStream_t s);
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
                               const u32 *tot, hipStream_t s);
-// mids[i] (start / len in records) -> keys at key_base[i] ..., out_nodes[16 i .. 16 i + 15]
-// heavy: one workgroup of eight waves per bucket (buckets of millions of k-mers) instead of one wave
-hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
-                            Node *out_nodes, hipStream_t s, bool heavy = false);
-
+// buckets sk_count does not take, expanded to keys in record order (no host step): slices of sk_flat_slice() records
+// per bucket (n_slices[i], then after an exclusive scan slice_first[i]; slice_rec0 = first record, slice_nrec = records),
+// k-mers per slice, after a scan the keys of slice s at key_base + slice_koff[s] and one key node per bucket
+int sk_flat_slice();
+// out[j] = mids[idx[j]] with child_base = kcount[idx[j]]; mids[idx[j]].len = 0
+hipError_t launch_sk_take_heavy(Node *mids, const u32 *idx, u32 n_heavy, const u32 *kcount, Node *out, hipStream_t s);
+hipError_t launch_sk_slice_count(const Node *buckets, u32 nb, u32 *n_slices, hipStream_t s);
+hipError_t launch_sk_slice_fill(const Node *buckets, u32 nb, const u32 *slice_first, u32 *slice_rec0, u32 *slice_nrec, hipStream_t s);
+hipError_t launch_sk_slice_kmers(const void *recs, const u32 *slice_rec0, const u32 *slice_nrec, u32 n_slices, u32 *slice_km,
+                                 hipStream_t s);
+hipError_t launch_sk_slice_nodes(const Node *buckets, u32 nb, const u32 *slice_first, const u32 *slice_koff, u32 n_slices,
+                                 const u32 *total_keys, u32 key_base, int k, bool check_kmers, Node *out, u64 *n_bad, hipStream_t s);
+hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const u32 *slice_nrec, const u32 *slice_koff, u32 key_base,
+                                 u32 n_slices, int k, u64 *keys, hipStream_t s);
 // every mid bucket's records regrouped by d2 from src into the same range of dst; out_nodes[16 i + j] = final bucket:
 // start / len in records, child_base = its k-mers
 hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s);

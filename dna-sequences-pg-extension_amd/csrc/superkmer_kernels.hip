@@ -12,9 +12,10 @@
 //   sk_hist0 / sk_scatter0   sweep the packed dna: hashes, window minima, runs -> records scattered
 //                            into C0 coarse buckets (1.8 B per k-mer instead of 8)
 //   sk_hist1 / sk_scatter1   records of a coarse bucket -> 2^b1 mid buckets
-//   sk_expand                a mid bucket's records -> keys, grouped by d2 into 16 nodes of ~3,800 keys
-//   ... then the ordinary tree takes over at level 2: plan -> leaves (an oversize node is split further
-//   by the generic levels, skew handling included).
+//   sk_regroup               a mid bucket's records regrouped by d2: 16 final buckets of ~2,900 k-mers
+//   sk_count                 a final bucket counted from its records in an LDS hash table; groups appended to the output
+//   sk_slice_kmers / sk_expand_flat   the buckets sk_count does not take (oversize; the heavy buckets of repeats) -> keys;
+//                            the ordinary tree takes over at level 2 (skew handling included)
 //
 // Keys meet their equals because the bucket is a function of the key; which bucket that is never shows in
 // the result.  Group order: nodes in bucket order, ascending inside a node -- NOT globally ascending, which
@@ -475,14 +476,6 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// sk_expand: one WAVE per mid bucket, no workgroup barrier anywhere.  Sweep A counts the bucket's k-mers per d2;
-// the bucket's key range (key_base[bucket], from the scan of kcount) is cut into 16 nodes accordingly.  Sweep B
-// takes 64 records at a time (the next 64 already requested), stages their keys grouped by d2 in the wave's
-// LDS slice and copies every group to its node's range, coalesced.
-constexpr int SKX_WAVES = 4;
-constexpr int SKX_NT = 64 * SKX_WAVES;
-
 // LDS written by one lane and read by another of the same wave: DS operations of a wave execute in program
 // order, so only the compiler has to be kept from reordering them
 __device__ __forceinline__ void sk_wave_fence()
@@ -503,160 +496,198 @@ __device__ __forceinline__ u32 row16_excl_scan(u32 x)
     return (u32)v - x;
 }
 
-// WPB = waves per bucket: 1 (a workgroup's waves take a bucket each) or SKX_HEAVY_WAVES (one workgroup per HEAVY bucket --
-// millions of k-mers of a repeat's minimizer --, every wave a slice of its records, the slices' places inside the 16
-// groups settled with one barrier after sweep A).
-constexpr int SKX_HEAVY_WAVES = 8;
-template <int WPB>
-__global__ __launch_bounds__(64 * (WPB == 1 ? SKX_WAVES : WPB)) void sk_expand_kernel(const Node *__restrict__ mids, u32 n_mids,
-                                                           const ull2_t *__restrict__ recs,
-                                                           const u32 *__restrict__ key_base, int k, u32 lmax,
-                                                           u64 *__restrict__ keys, Node *__restrict__ out_nodes, int dbg)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-    __shared__ u32 wcnt[WPB == 1 ? 1 : WPB][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 i = WPB == 1 ? blockIdx.x * SKX_WAVES + (u32)wave : blockIdx.x;
-    if (i >= n_mids)
-        return;                                   // (WPB == 1: whole waves leave, nothing below synchronises across waves)
-    const u32 stage_keys = 64u * lmax;
-    unsigned char *mine = sk_smem + (size_t)wave * ((size_t)stage_keys * 8 + 5 * 16 * 4);
-    u64 *stage = reinterpret_cast<u64 *>(mine);
-    u32 *sc = reinterpret_cast<u32 *>(mine + (size_t)stage_keys * 8);   // keys per d2 (sweep A: of the bucket; B: of the batch)
-    u32 *scur = sc + 16, *nbase = sc + 32, *done = sc + 48;
-    Node nd = mids[i];
-    const u64 kmask = kmer_mask(k);
-    if (WPB > 1) {                                // this wave's slice of the bucket's records (whole batches of 64)
-        const u32 per = ((nd.len + WPB - 1) / WPB + 63u) & ~63u;
-        const u32 s0 = (u32)wave * per < nd.len ? (u32)wave * per : nd.len;
-        const u32 s1 = s0 + per < nd.len ? s0 + per : nd.len;
-        nd.start += s0;
-        nd.len = s1 - s0;
-    }
-    const ull2_t *src = recs + (u64)nd.start;
+// ------------------------------------------------------------------------------------------------
+// Buckets that sk_count does not take (more k-mers, records or quads than its tables hold; the heavy mid buckets of long
+// repeats with millions of k-mers) are expanded to keys in record order by many waves at once, with no host step
+// in between: a bucket's records are cut into slices of SKF_SLICE records (sk_slice_count -> scan -> sk_slice_fill),
+// sk_slice_kmers sums every slice's k-mers, a scan of the sums gives every slice its key offset and every bucket its
+// key range (sk_slice_nodes: one key node per bucket, which the ordinary levels split with their skew paths), and
+// sk_expand_flat expands slice by slice (64 records at a time: lengths -> wave prefix -> keys staged in LDS -> one
+// contiguous copy).
+constexpr int SKF_SLICE = 4096;
+int sk_flat_slice() { return SKF_SLICE; }
 
-    if (lane < 16) {
-        sc[lane] = 0;
-        done[lane] = 0;
+__global__ __launch_bounds__(256) void sk_slice_count_kernel(const Node *__restrict__ buckets, u32 nb, u32 *__restrict__ n_slices)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb)
+        n_slices[i] = (buckets[i].len + (u32)SKF_SLICE - 1u) / (u32)SKF_SLICE;
+}
+
+// one wave per bucket: its slices' first records and record counts, at slice_first[bucket]
+__global__ __launch_bounds__(256) void sk_slice_fill_kernel(const Node *__restrict__ buckets, u32 nb,
+                                                            const u32 *__restrict__ slice_first, u32 *__restrict__ slice_rec0,
+                                                            u32 *__restrict__ slice_nrec)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nb)
+        return;
+    const u32 start = buckets[i].start, len = buckets[i].len, s0 = slice_first[i];
+    const u32 ns = (len + (u32)SKF_SLICE - 1u) / (u32)SKF_SLICE;
+    for (u32 j = lane; j < ns; j += 64) {
+        slice_rec0[s0 + j] = start + j * (u32)SKF_SLICE;
+        slice_nrec[s0 + j] = min((u32)SKF_SLICE, len - j * (u32)SKF_SLICE);
     }
-    sk_wave_fence();
-    // (eight independent loads per lane in flight: one wave per bucket has little else to hide their latency)
-    for (u32 r0 = 0; r0 < nd.len; r0 += 64 * 8) {
-        u64 m[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const u32 r = r0 + (u32)q * 64 + (u32)lane;
-            m[q] = r < nd.len ? __builtin_nontemporal_load(&reinterpret_cast<const u64 *>(src + r)[1]) : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            if (r0 + (u32)q * 64 + (u32)lane < nd.len)
-                atomicAdd(&sc[(u32)(m[q] >> 59) & 15u], (u32)((m[q] >> 44) & 31) + 1u);
-    }
-    sk_wave_fence();
-    const u32 kb = key_base[i];
-    if (WPB > 1) {
-        // the slices' k-mers per d2 -> the bucket's totals (the 16 nodes) and every slice's place inside each node
-        if (lane < 16)
-            wcnt[wave][lane] = sc[lane];
-        __syncthreads();
-        u32 tot = 0, mine_before = 0;
-        if (lane < 16)
-            for (int w = 0; w < WPB; w++) {
-                const u32 t = wcnt[w][lane];
-                mine_before += w < wave ? t : 0u;
-                tot += t;
-            }
-        const u32 ex = row16_excl_scan(tot);
-        if (lane < 16) {
-            nbase[lane] = ex;
-            done[lane] = mine_before;
-            if (wave == 0) {
-                Node o;
-                o.start = kb + ex;
-                o.len = tot;
-                o.meta = (u32)(2 * k);
-                o.split = 0;
-                o.prefix = 0;
-                o.child_base = 0;
-                o.chunk_base = 0;
-                out_nodes[(u64)i * 16 + lane] = o;
-            }
-        }
-    } else {
-        const u32 v = lane < 16 ? sc[lane] : 0u;
-        const u32 ex = row16_excl_scan(v);
-        if (lane < 16) {
-            nbase[lane] = ex;
-            Node o;
-            o.start = kb + ex;
-            o.len = v;
-            o.meta = (u32)(2 * k);                // no key bit is fixed: the leaves sort on the top bits; buffer 0
-            o.split = 0;
-            o.prefix = 0;
-            o.child_base = 0;
-            o.chunk_base = 0;
-            out_nodes[(u64)i * 16 + lane] = o;
-        }
-    }
-    // the records of the next SKX_AHEAD batches are always in flight
-    constexpr int SKX_AHEAD = 4;
-    ull2_t ring[SKX_AHEAD];
-#pragma unroll
-    for (int q = 0; q < SKX_AHEAD; q++) {
-        ring[q].x = 0;
-        ring[q].y = 0;
-        if ((u32)q * 64 + (u32)lane < nd.len)
-            ring[q] = src[q * 64 + lane];
-    }
-    for (u32 g0 = 0; g0 < nd.len; g0 += 64 * SKX_AHEAD)
-#pragma unroll
-    for (int gq = 0; gq < SKX_AHEAD; gq++) {
-        const u32 b0 = g0 + (u32)gq * 64;
-        if (b0 >= nd.len)                                  // wave-uniform
-            break;
-        const ull2_t rec = ring[gq];
-        const bool have = b0 + (u32)lane < nd.len;
-        if (b0 + 64 * SKX_AHEAD + (u32)lane < nd.len)
-            ring[gq] = src[b0 + 64 * SKX_AHEAD + lane];
+}
+
+__global__ __launch_bounds__(256) void sk_slice_kmers_kernel(const ull2_t *__restrict__ recs, const u32 *__restrict__ slice_rec0,
+                                                             const u32 *__restrict__ slice_nrec, u32 n_slices,
+                                                             u32 *__restrict__ slice_km)
+{
+    const int lane = threadIdx.x & 63;
+    const u32 si = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (si >= n_slices)
+        return;
+    const u64 *hi = reinterpret_cast<const u64 *>(recs + (u64)slice_rec0[si]) + 1;
+    const u32 n = slice_nrec[si];
+    u32 sum = 0;
+    for (u32 r = lane; r < n; r += 64)
+        sum += (u32)((__builtin_nontemporal_load(&hi[(u64)r * 2]) >> 44) & 31) + 1u;
+    sum = wave_sum(sum);
+    if (lane == 0)
+        slice_km[si] = sum;
+}
+
+// key node of bucket i: the keys of its slices, [key_base + slice_koff[first slice], ... of the next bucket).
+// expect_kmers (buckets[i].child_base, the partition's own count) must agree: *n_bad counts the buckets where not.
+__global__ __launch_bounds__(256) void sk_slice_nodes_kernel(const Node *__restrict__ buckets, u32 nb,
+                                                             const u32 *__restrict__ slice_first, const u32 *__restrict__ slice_koff,
+                                                             u32 n_slices, const u32 *__restrict__ total_keys, u32 key_base, int k,
+                                                             int check_kmers, Node *__restrict__ out,
+                                                             unsigned long long *__restrict__ n_bad)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb)
+        return;
+    const u32 s0 = slice_first[i], s1 = i + 1 < nb ? slice_first[i + 1] : n_slices;
+    const u32 k0 = s0 < n_slices ? slice_koff[s0] : *total_keys, k1 = s1 < n_slices ? slice_koff[s1] : *total_keys;
+    Node nd;
+    nd.prefix = 0;
+    nd.start = key_base + k0;
+    nd.len = k1 - k0;
+    nd.meta = (u32)(2 * k);                      // no key bit is fixed; buffer 0
+    nd.split = 0;
+    nd.child_base = 0;
+    nd.chunk_base = 0;
+    out[i] = nd;
+    if (check_kmers && buckets[i].child_base != k1 - k0)
+        atomicAdd(n_bad, 1ull);
+}
+
+__global__ __launch_bounds__(256) void sk_expand_flat_kernel(const ull2_t *__restrict__ recs, const u32 *__restrict__ slice_rec0,
+                                                             const u32 *__restrict__ slice_nrec,
+                                                             const u32 *__restrict__ slice_koff, u32 key_base, u32 n_slices, int k,
+                                                             u32 lmax, u64 *__restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char skf_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 si = blockIdx.x * 4 + (u32)wave;
+    if (si >= n_slices)
+        return;                                   // (whole waves: nothing below synchronises across waves)
+    u64 *stage = reinterpret_cast<u64 *>(skf_smem) + (size_t)wave * 64 * lmax;
+    const ull2_t *src = recs + (u64)slice_rec0[si];
+    const u32 n = slice_nrec[si];
+    const u64 kmask = kmer_mask(k);
+    u64 out = (u64)key_base + slice_koff[si];
+    ull2_t nxt;
+    nxt.x = nxt.y = 0;
+    if ((u32)lane < n)
+        nxt = src[lane];
+    for (u32 b0 = 0; b0 < n; b0 += 64) {
+        const ull2_t rec = nxt;
+        const bool have = b0 + (u32)lane < n;
+        if (b0 + 64 + (u32)lane < n)
+            nxt = src[b0 + 64 + lane];
         const u32 len = have ? (u32)((rec.y >> 44) & 31) + 1u : 0u;
-        const u32 d2 = (u32)(rec.y >> 59) & 15u;
-        if (lane < 16)
-            sc[lane] = 0;
+        const u32 inc = wave_incl_scan(len);
+        const u32 n_keys = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        const u32 o = inc - len;
+        const u64 hi = rec.y & (((u64)1 << 44) - 1);
+        for (u32 j = 0; j < len; j++)
+            stage[o + j] = funnel(rec.x, hi, 2 * j) & kmask;
         sk_wave_fence();
-        if (have)
-            atomicAdd(&sc[d2], len);
+        for (u32 s = lane; s < n_keys; s += 64)
+            __builtin_nontemporal_store(stage[s], &keys[out + s]);
         sk_wave_fence();
-        const u32 cnt = lane < 16 ? sc[lane] : 0u;
-        const u32 sbv = row16_excl_scan(cnt);              // lanes 0..15: where d2 = lane starts in the stage
-        const u32 n_keys = (u32)__builtin_amdgcn_readlane((int)(sbv + cnt), 15);
-        u32 adjv = 0;                                      // destination of stage slot s of d2 = lane: adjv + s
-        if (lane < 16) {
-            scur[lane] = sbv;
-            adjv = kb + nbase[lane] + done[lane] - sbv;
-            done[lane] += cnt;
-        }
-        sk_wave_fence();
-        if (have && !(dbg & 8)) {
-            const u32 o = atomicAdd(&scur[d2], len);
-            const u64 hi = rec.y & (((u64)1 << 44) - 1);
-            for (u32 j = 0; j < len; j++)
-                stage[o + j] = funnel(rec.x, hi, 2 * j) & kmask;
-        }
-        sk_wave_fence();
-        if (dbg & 16)
-            continue;
-        // copy out group by group: bounds and destination offsets as scalars, a group is rarely longer than 64 keys
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const u32 g0 = (u32)__builtin_amdgcn_readlane((int)sbv, g);
-            const u32 g1 = g < 15 ? (u32)__builtin_amdgcn_readlane((int)sbv, g + 1) : n_keys;
-            const u32 a = (u32)__builtin_amdgcn_readlane((int)adjv, g);
-            for (u32 s = g0 + lane; s < g1; s += 64)
-                __builtin_nontemporal_store(stage[s], &keys[(u64)(a + s)]);
-        }
-        sk_wave_fence();                                   // the stage and adj are rewritten by the next batch
+        out += n_keys;
     }
+}
+
+// heavy mid buckets leave the record path: out[j] = mids[idx[j]] with child_base = its k-mers; the list entry is emptied
+__global__ __launch_bounds__(256) void sk_take_heavy_kernel(Node *__restrict__ mids, const u32 *__restrict__ idx, u32 n_heavy,
+                                                            const u32 *__restrict__ kcount, Node *__restrict__ out)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_heavy)
+        return;
+    const u32 i = idx[j];
+    Node nd = mids[i];
+    nd.child_base = kcount[i];
+    out[j] = nd;
+    mids[i].len = 0;
+}
+
+hipError_t launch_sk_take_heavy(Node *mids, const u32 *idx, u32 n_heavy, const u32 *kcount, Node *out, hipStream_t s)
+{
+    if (n_heavy == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_take_heavy_kernel, dim3((n_heavy + 255) / 256), dim3(256), 0, s, mids, idx, n_heavy, kcount, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_slice_count(const Node *buckets, u32 nb, u32 *n_slices, hipStream_t s)
+{
+    if (nb == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_slice_count_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, buckets, nb, n_slices);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_slice_fill(const Node *buckets, u32 nb, const u32 *slice_first, u32 *slice_rec0, u32 *slice_nrec, hipStream_t s)
+{
+    if (nb == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_slice_fill_kernel, dim3((nb + 3) / 4), dim3(256), 0, s, buckets, nb, slice_first, slice_rec0, slice_nrec);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_slice_kmers(const void *recs, const u32 *slice_rec0, const u32 *slice_nrec, u32 n_slices, u32 *slice_km,
+                                 hipStream_t s)
+{
+    if (n_slices == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_slice_kmers_kernel, dim3((n_slices + 3) / 4), dim3(256), 0, s, reinterpret_cast<const ull2_t *>(recs),
+                       slice_rec0, slice_nrec, n_slices, slice_km);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_slice_nodes(const Node *buckets, u32 nb, const u32 *slice_first, const u32 *slice_koff, u32 n_slices,
+                                 const u32 *total_keys, u32 key_base, int k, bool check_kmers, Node *out, u64 *n_bad, hipStream_t s)
+{
+    if (nb == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_slice_nodes_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, buckets, nb, slice_first, slice_koff, n_slices,
+                       total_keys, key_base, k, check_kmers ? 1 : 0, out, reinterpret_cast<unsigned long long *>(n_bad));
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const u32 *slice_nrec, const u32 *slice_koff, u32 key_base,
+                                 u32 n_slices, int k, u64 *keys, hipStream_t s)
+{
+    if (n_slices == 0)
+        return hipSuccess;
+    u32 lmax = (u32)(54 - k + 1);
+    if (lmax > 32)
+        lmax = 32;
+    const size_t smem = (size_t)4 * 64 * lmax * 8;
+    const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_flat_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * 64 * 32 * 8));
+    if (ae != hipSuccess)
+        return ae;
+    hipLaunchKernelGGL(sk_expand_flat_kernel, dim3((n_slices + 3) / 4), dim3(256), smem, s, reinterpret_cast<const ull2_t *>(recs),
+                       slice_rec0, slice_nrec, slice_koff, key_base, n_slices, k, lmax, keys);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1155,31 +1186,5 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
     return hipGetLastError();
 }
 
-hipError_t launch_sk_expand(const Node *mids, u32 n_mids, const void *recs, const u32 *key_base, int k, u64 *keys,
-                            Node *out_nodes, hipStream_t s, bool heavy)
-{
-    if (n_mids == 0)
-        return hipSuccess;
-    u32 lmax = (u32)(54 - k + 1);
-    if (lmax > 32)
-        lmax = 32;
-    const size_t per_wave = (size_t)64 * lmax * 8 + 5 * 16 * 4, per_wave_max = (size_t)64 * 32 * 8 + 5 * 16 * 4;
-    // (set per call: the attribute is per device and cheap to set)
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SKX_WAVES * per_wave_max));
-    if (ae == hipSuccess)
-        ae = hipFuncSetAttribute(reinterpret_cast<const void *>(sk_expand_kernel<SKX_HEAVY_WAVES>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SKX_HEAVY_WAVES * per_wave_max));
-    if (ae != hipSuccess)
-        return ae;
-    if (heavy)
-        hipLaunchKernelGGL(sk_expand_kernel<SKX_HEAVY_WAVES>, dim3(n_mids), dim3(64 * SKX_HEAVY_WAVES),
-                           SKX_HEAVY_WAVES * per_wave, s, mids, n_mids, reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax,
-                           keys, out_nodes, sk_dbg());
-    else
-        hipLaunchKernelGGL(sk_expand_kernel<1>, dim3((n_mids + SKX_WAVES - 1) / SKX_WAVES), dim3(SKX_NT), SKX_WAVES * per_wave,
-                           s, mids, n_mids, reinterpret_cast<const ull2_t *>(recs), key_base, k, lmax, keys, out_nodes, sk_dbg());
-    return hipGetLastError();
-}
 
 }  // namespace dnagpu

@@ -10,7 +10,7 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 with pkg.Context(0) as ctx:
-    d = ctx.synth(0xD2A0003, n)
+    d = ctx.synth(0xD2A0003, n, motif_len=int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     for _ in range(iters):
         h = ctx.count_kmers_unordered(d, k)
         print("distinct", h.distinct)
