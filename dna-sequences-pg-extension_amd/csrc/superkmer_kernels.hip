@@ -66,6 +66,13 @@ __device__ __forceinline__ SkDigits sk_digits(u32 hmin, u32 c0, u32 b1mask)
     return r;
 }
 
+// timing ablations (results invalid) exist in the diagnostic build (make STAMPS=1) only
+#ifdef DNAGPU_STAMPS
+#define SK_DBG(bit) ((dbg & (bit)) != 0)
+#else
+#define SK_DBG(bit) false
+#endif
+
 __device__ __forceinline__ u32 wave_incl_max(u32 x)
 {
     int v = (int)x;                               // values are row indices + 1: small and non-negative
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                 __syncthreads();
                 continue;
             }
-            if (!(dbg & 2))
+            if (!SK_DBG(2))
                 for (u32 e = tid; e < tile_recs; e += SK_NT) {
                     u32 wq = 0;
 #pragma unroll
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     ull2_t r;
                     r.x = lo;
                     r.y = hi;
-                    if (!(dbg & 1))
+                    if (!SK_DBG(1))
                         recs[gslot] = r;
                     else if (r.x == 0x1234567 && r.y == 0x89)
                         recs[0] = r;
@@ -862,7 +869,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
     __shared__ u64 sh_obase[2];
-    __shared__ u32 ones_cnt[2];
+    __shared__ u32 ones_cnt[2], copy_seen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 lq = blockIdx.x;
     if (lq >= n_list)
@@ -871,8 +878,10 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         tab[q] = SKC_EMPTY;
     for (int q = tid; q < SKC_SLOTS / 2; q += SKC_NT)
         cnt2[q] = 0;
-    if (tid < 2)
+    if (tid < 2) {
         ones_cnt[tid] = 0;
+        copy_seen[tid] = 0;
+    }
     const u64 kmask = kmer_mask(k);
     const u64 below = ((u64)1 << lane) - 1;
     u32 li = list[lq];
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         for (int q = 0; q < KEEP; q++) {
             const bool mine = (p_mask >> q) & 1u;
             const u64 b = __ballot(mine);
-            if (mine && !(dbg & 64)) {
+            if (mine && !SK_DBG(64)) {
                 const u64 o = obase + run + (u32)__popcll(b & below);
                 out_keys[o] = pk[q];
                 out_counts[o] = pc[q];
@@ -973,7 +982,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                     const u64 kv = slo & kmask;
                     slo = (slo >> 2) | (shi << 62);
                     shi >>= 2;
-                    if (dbg & 32) {
+                    if (SK_DBG(32)) {
                         c_mask |= (kv & 1) ? 1u << q : 0u;
                         ck[q] = kv;
                     } else if (kv == SKC_EMPTY) {
@@ -991,6 +1000,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                             }
                             if (old == kv) {       // a copy of a key already in the table: only copies are counted beside it
                                 atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
+                                copy_seen[par] = 1u;
                                 break;
                             }
                             slot = slot + 1 == (u32)SKC_SLOTS ? 0u : slot + 1;
@@ -1010,16 +1020,20 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
         u32 before = 0, D = 0;
         sk_wave_prefix16(wclaim[par], WAVES, wave, lane, before, D);
+        const bool any_copy = copy_seen[par] != 0; // (random sequence: no bucket has one, and the count table is not read)
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
             pk[q] = ck[q];
             pc[q] = 0;
             if ((c_mask >> q) & 1u) {
-                const u32 copies = cnt16[cslot[q]];
-                pc[q] = 1u + copies;
+                pc[q] = 1u;
                 tab[cslot[q]] = SKC_EMPTY;
-                if (copies)
-                    cnt16[cslot[q]] = 0;
+                if (any_copy) {
+                    const u32 copies = cnt16[cslot[q]];
+                    pc[q] = 1u + copies;
+                    if (copies)
+                        cnt16[cslot[q]] = 0;
+                }
             }
         }
         p_mask = c_mask;
@@ -1029,7 +1043,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         p_li = li;
         if (tid == 0) {
             ob_pending = atomicAdd(cursor, (unsigned long long)p_groups);
-            ones_cnt[par ^ 1] = 0;                 // (the other parity's counter: its bucket has been emitted)
+            ones_cnt[par ^ 1] = 0;                 // (the other parity's counters: its bucket has been emitted)
+            copy_seen[par ^ 1] = 0;
         }
         have_prev = true;
         par ^= 1;
@@ -1053,10 +1068,9 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const v
 {
     if (n_list == 0)
         return hipSuccess;
-    int dev = 0, n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
+    int dev = 0, n_cu = 256, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        n_cu = v;
     const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
     hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, n_list, reinterpret_cast<const ull2_t *>(recs),
                        k, reinterpret_cast<unsigned long long *>(cursor), seg_off, seg_cnt, out_keys, out_counts, sk_dbg());
