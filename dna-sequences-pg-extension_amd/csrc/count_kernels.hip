@@ -2093,8 +2093,8 @@ __global__ __launch_bounds__(1024) void dense_compact_kernel(const u32 *__restri
 
 int dense_max_bits() { return DENSE_MAX_BITS; }
 
-hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, u64 *out_keys,
-                              u32 *out_counts, u64 *n_out, hipStream_t s)
+// table[key] = windows of [first, first + count) that hold key (the table is zeroed here)
+hipError_t launch_dense_table(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, hipStream_t s)
 {
     if (!func_attrs_ready(FA_DENSE)) {
         const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_count_kernel),
@@ -2106,6 +2106,8 @@ hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 coun
     hipError_t e = hipMemsetAsync(table, 0, ((size_t)1 << bits) * 4, s);
     if (e != hipSuccess)
         return e;
+    if (count == 0)
+        return hipSuccess;
     const u32 passes = bits > 15 ? (1u << (bits - 15)) : 1u;
     const u64 per_wg = (u64)1024 * 16;
     u32 grid = (u32)std::min<u64>((count + per_wg - 1) / per_wg, 256);
@@ -2115,7 +2117,35 @@ hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 coun
     for (u32 pass = 0; pass < passes; pass++)
         hipLaunchKernelGGL(dense_count_kernel, dim3(grid), dim3(1024), lds, s, words, n_words, first, count, bits, pass,
                            table);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_compact(const u32 *table, int bits, u64 *out_keys, u32 *out_counts, u64 *n_out, hipStream_t s)
+{
     hipLaunchKernelGGL(dense_compact_kernel, dim3(1), dim3(1024), 0, s, table, bits, out_keys, out_counts, n_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, u64 *out_keys,
+                              u32 *out_counts, u64 *n_out, hipStream_t s)
+{
+    const hipError_t e = launch_dense_table(words, n_words, first, count, bits, table, s);
+    return e != hipSuccess ? e : launch_dense_compact(table, bits, out_keys, out_counts, n_out, s);
+}
+
+// dst[i] += src[i] (the partial tables of a multi-GPU dense count without RCCL)
+__global__ __launch_bounds__(256) void table_add_kernel(u32 *__restrict__ dst, const u32 *__restrict__ src, u32 n)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] += src[i];
+}
+
+hipError_t launch_table_add(u32 *dst, const u32 *src, u32 n, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(table_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
     return hipGetLastError();
 }
 

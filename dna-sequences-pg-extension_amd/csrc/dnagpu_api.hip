@@ -1546,6 +1546,12 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     return DNAGPU_OK;
 }
 
+// short k-mers (2k <= dense_max_bits()) of enough rows to pay for the table passes and for compacting the table: no tree
+static bool dense_pays(u64 n, int k)
+{
+    return 2 * k <= dense_max_bits() && n > (u64)LEAF_CAP && n >= ((u64)(2 * k > 16 ? 64 : 4) << (2 * k));
+}
+
 // any_order: the caller does not need ascending keys across the whole result (dnagpu_count_kmers_unordered): long
 // k-mers of long sequences then go through the super-k-mer engine
 constexpr u64 SK_MIN_ROWS = (u64)1 << 22;
@@ -1582,8 +1588,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         }
         prof_begin(ctx);                         // a bucket too heavy for the engine: the ordinary tree from scratch
     }
-    if (dna && n_owners == 1 && fixed_bits == 0 && 2 * k <= dense_max_bits() && n > (u64)LEAF_CAP &&
-        n >= ((u64)(2 * k > 16 ? 64 : 4) << (2 * k))) {   // (enough rows to pay for the passes and for compacting the table)
+    if (dna && n_owners == 1 && fixed_bits == 0 && dense_pays(n, k)) {
         // short k-mers: the histogram is a table of at most 262,144 counters filled straight from the
         // packed sequence (no key is ever written); one segment, keys ascending
         PoolScope ps(ctx);
@@ -1980,6 +1985,7 @@ struct RcclApi {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -1998,10 +2004,11 @@ struct RcclApi {
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
+        if (!CommInitAll || !CommDestroy || !AllGather || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) {
             dlclose(lib);
             lib = nullptr;
             return false;
@@ -2239,6 +2246,150 @@ static int multi_gather(dnagpu_multi *m, const dnagpu_multi_dna *d)
     return DNAGPU_OK;
 }
 
+// Short k-mers on N ranks (a sum-reduce of the 4^k table): nothing is gathered.  Rank r counts the
+// rows that START in its own chunk into a table of 4^k counters (the k-1 <= 8 bases a row may reach into the next
+// chunk are one word, copied from the neighbour), the tables are summed onto rank 0 (ncclReduce, or peer copies and
+// adds), and rank 0 compacts: hists[0] holds the whole result in ascending key order, the other ranks' are empty.
+static int multi_count_dense(dnagpu_multi *m, const dnagpu_multi_dna *d, int k, u64 first, u64 count, dnagpu_hist **hists)
+{
+    const int bits = 2 * k;
+    const size_t n_bins = (size_t)1 << bits;
+    std::vector<u32 *> table((size_t)m->n, nullptr);
+    u32 *scratch = nullptr;
+    int rc = DNAGPU_OK;
+    auto cleanup = [&]() {
+        for (int r = 0; r < m->n; r++)
+            pool_free(m->ctx[(size_t)r], table[(size_t)r]);
+        pool_free(m->ctx[0], scratch);
+    };
+    for (int r = 0; r < m->n && rc == DNAGPU_OK; r++) {
+        dnagpu_ctx *c = m->ctx[(size_t)r];
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess)
+            rc = pool_alloc_t(c, n_bins, &table[(size_t)r]);
+        if (e == hipSuccess && rc == DNAGPU_OK) {
+            const u64 w_lo = std::min((u64)r * d->per, d->n_words), w_hi = std::min((u64)(r + 1) * d->per, d->n_words);
+            const u64 row_lo = std::max(first, w_lo * 32), row_hi = std::min(first + count, w_hi * 32);
+            if (r + 1 < m->n && w_hi < d->n_words && row_hi > row_lo) {
+                // the neighbour's first word (its chunk is resident since the upload; gather space on this rank)
+                const int src = r + 1;
+                u64 *to = d->full[(size_t)r] + w_hi;
+                const u64 *from = d->full[(size_t)src] + w_hi;
+                e = m->dev[(size_t)src] == m->dev[(size_t)r]
+                        ? hipMemcpyAsync(to, from, 8, hipMemcpyDeviceToDevice, c->stream)
+                        : hipMemcpyPeerAsync(to, m->dev[(size_t)r], from, m->dev[(size_t)src], 8, c->stream);
+            }
+            if (e == hipSuccess)
+                e = launch_dense_table(d->full[(size_t)r], d->n_words, row_lo, row_hi > row_lo ? row_hi - row_lo : 0, bits,
+                                       table[(size_t)r], c->stream);
+        }
+        if (e != hipSuccess) {
+            set_err("dense multi count (rank %d): %s", r, hipGetErrorString(e));
+            rc = DNAGPU_ERR_HIP;
+        }
+    }
+    if (rc == DNAGPU_OK && m->n > 1) {
+        if (m->rccl) {
+            ncclResult_t nr = m->api.GroupStart();
+            for (int r = 0; r < m->n && nr == ncclSuccess; r++)
+                nr = m->api.Reduce(table[(size_t)r], table[(size_t)r], n_bins, ncclUint32, ncclSum, 0, m->comms[(size_t)r],
+                                   m->ctx[(size_t)r]->stream);
+            const ncclResult_t ne = m->api.GroupEnd();
+            if (nr != ncclSuccess || ne != ncclSuccess) {
+                set_err("ncclReduce: %s", m->api.GetErrorString(nr != ncclSuccess ? nr : ne));
+                rc = DNAGPU_ERR_HIP;
+            }
+        } else {
+            dnagpu_ctx *c0 = m->ctx[0];
+            hipError_t e = hipSuccess;
+            for (int r = 1; r < m->n && e == hipSuccess; r++) {       // (the partial table of rank r is complete)
+                e = hipSetDevice(m->ctx[(size_t)r]->device);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(m->ctx[(size_t)r]->stream);
+            }
+            if (e == hipSuccess)
+                e = hipSetDevice(c0->device);
+            if (e == hipSuccess)
+                rc = pool_alloc_t(c0, n_bins, &scratch);
+            for (int r = 1; r < m->n && e == hipSuccess && rc == DNAGPU_OK; r++) {
+                e = m->dev[(size_t)r] == m->dev[0]
+                        ? hipMemcpyAsync(scratch, table[(size_t)r], n_bins * 4, hipMemcpyDeviceToDevice, c0->stream)
+                        : hipMemcpyPeerAsync(scratch, m->dev[0], table[(size_t)r], m->dev[(size_t)r], n_bins * 4, c0->stream);
+                if (e == hipSuccess)
+                    e = launch_table_add(table[0], scratch, (u32)n_bins, c0->stream);
+            }
+            if (e != hipSuccess) {
+                set_err("dense multi count (sum): %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            }
+        }
+    }
+    // rank 0: the table -> ascending (key, count) groups, one segment
+    if (rc == DNAGPU_OK) {
+        dnagpu_ctx *c0 = m->ctx[0];
+        PoolScope ps(c0);
+        u32 *oc = nullptr, *seg_cnt = nullptr;
+        u64 *ok = nullptr, *seg_off = nullptr, *n_out = nullptr;
+        hipError_t e = hipSetDevice(c0->device);
+        rc = ps.alloc(n_bins, &ok);
+        if (rc == DNAGPU_OK) rc = ps.alloc(n_bins, &oc);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &seg_off);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &seg_cnt);
+        if (rc == DNAGPU_OK) rc = ps.alloc(1, &n_out);
+        u64 D = 0;
+        if (rc == DNAGPU_OK) {
+            if (e == hipSuccess)
+                e = launch_dense_compact(table[0], bits, ok, oc, n_out, c0->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(&D, n_out, 8, hipMemcpyDeviceToHost, c0->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(c0->stream);
+            const u64 zero = 0;
+            const u32 d32 = (u32)D;
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(seg_off, &zero, 8, hipMemcpyHostToDevice, c0->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(seg_cnt, &d32, 4, hipMemcpyHostToDevice, c0->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(c0->stream);
+            if (e != hipSuccess) {
+                set_err("dense multi count (compact): %s", hipGetErrorString(e));
+                rc = DNAGPU_ERR_HIP;
+            }
+        }
+        for (int r = 0; r < m->n && rc == DNAGPU_OK; r++) {
+            hists[r] = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, r == 0 ? count : 0, nullptr, nullptr, nullptr, 0, true};
+            if (!hists[r])
+                rc = DNAGPU_ERR_OOM;
+        }
+        if (rc == DNAGPU_OK) {
+            dnagpu_hist *h = hists[0];
+            h->n_distinct = D;
+            h->keys = ok;
+            h->counts = oc;
+            h->seg_off = seg_off;
+            h->seg_cnt = seg_cnt;
+            h->n_segs = 1;
+            ps.release(ok);
+            ps.release(oc);
+            ps.release(seg_off);
+            ps.release(seg_cnt);
+        } else {
+            for (int r = 0; r < m->n; r++) {
+                delete hists[r];
+                hists[r] = nullptr;
+            }
+        }
+    }
+    // the other ranks' streams may still hold the reduce: their tables go back to the pools behind it
+    for (int r = 1; r < m->n; r++)
+        if (hipSetDevice(m->ctx[(size_t)r]->device) == hipSuccess)
+            (void)hipStreamSynchronize(m->ctx[(size_t)r]->stream);
+    (void)hipSetDevice(m->ctx[0]->device);
+    cleanup();
+    return rc;
+}
+
 extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                                   dnagpu_hist **hists)
 {
@@ -2248,6 +2399,8 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     for (int r = 0; r < m->n; r++)
         hists[r] = nullptr;
     RC_TRY(check_range(dna->view[0], k, first, count));
+    if (dense_pays(count, k))
+        return multi_count_dense(m, dna, k, first, count, hists);
     RC_TRY(multi_gather(m, dna));
     // one host thread per rank: the level loop of a count reads counters back between levels, so the ranks
     // only run concurrently when each is driven by its own thread (device selection is per thread)

@@ -136,6 +136,10 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_sma
 int dense_max_bits();
 hipError_t launch_dense_count(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, u64 *out_keys,
                               u32 *out_counts, u64 *n_out, hipStream_t s);
+// the two halves of it (a multi-GPU dense count sums the ranks' tables in between), and dst[i] += src[i]
+hipError_t launch_dense_table(const u64 *words, u64 n_words, u64 first, u64 count, int bits, u32 *table, hipStream_t s);
+hipError_t launch_dense_compact(const u32 *table, int bits, u64 *out_keys, u32 *out_counts, u64 *n_out, hipStream_t s);
+hipError_t launch_table_add(u32 *dst, const u32 *src, u32 n, hipStream_t s);
 // groups [first, first+count) of the ascending-key view -> dst arrays
 hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u32 *seg_pre, u32 n_leaves,
                                 u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,

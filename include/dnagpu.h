@@ -269,7 +269,11 @@ void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d);
  * dnagpu_count_kmers_owned) in its own host thread.  hists[r] (n entries, caller's array) = rank r's
  * histogram, living on rank r's device; the ranks' ascending downloads concatenated in rank order are the
  * global result in ascending key order, sum of dnagpu_hist_total = count.  Free each with
- * dnagpu_hist_free(dnagpu_multi_ctx(m, r), hists[r]). */
+ * dnagpu_hist_free(dnagpu_multi_ctx(m, r), hists[r]).
+ * Short k-mers (k <= 9 with enough rows, the single-GPU table path's rule) gather nothing: rank r counts the rows
+ * that start in its own chunk into a table of 4^k counters (one word of halo from its neighbour), the tables
+ * are summed onto rank 0 (ncclReduce, or peer copies + adds) and compacted there: hists[0] then holds the whole
+ * result, the other ranks' histograms are empty -- the same concatenation property. */
 int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                        dnagpu_hist **hists);
 

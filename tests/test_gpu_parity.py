@@ -841,6 +841,10 @@ def test_count_multi_rccl_one_rank(pkg, ctx):
         ok, oc = orc.count_kmers(words, n, k)
         check_hist(hs[0], ok, oc, "multi rccl one rank")
         hs[0].free()
+        hs = m.count(d, 8)                          # short k-mers: the table path (ncclReduce of the 4^k counters)
+        ok, oc = orc.count_kmers(words, n, 8)
+        check_hist(hs[0], ok, oc, "multi rccl one rank, dense")
+        hs[0].free()
         m.dna_free(d)
     with pytest.raises(pkg.DnaGpuError):
         pkg.Multi([0, 0], pkg.MULTI_RCCL)          # RCCL needs distinct devices
