@@ -1468,7 +1468,7 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
         Node *knodes = nullptr;
         RC_TRY(ps.alloc((size_t)tree_keys, &kbuf));
         RC_TRY(ps.alloc((size_t)n_tree, &knodes));
-        prof_mark(ctx, "sk_expand");
+        prof_mark(ctx, "sk_expand_flat");
         // the final buckets live in `recs`, the heavy mid buckets in heavy.recs -> two slice lists; the key ranges: the
         // oversize final buckets in list order, the heavy buckets behind them
         for (int part = 0; part < 2; part++) {
