@@ -17,6 +17,7 @@ from .binding import (  # noqa: F401
     DnaGpuError,
     Filter,
     Hist,
+    Records,
     MULTI_AUTO,
     MULTI_COPY,
     MULTI_RCCL,

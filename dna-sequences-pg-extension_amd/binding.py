@@ -92,6 +92,17 @@ def lib():
     L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_count_kmers_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_hist_is_sorted.argtypes = [vp]
+    L.dnagpu_sk_buckets.argtypes = [vp, C.c_uint64, C.c_int]
+    L.dnagpu_sk_records.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_records_buckets.argtypes = [vp]
+    L.dnagpu_records_buckets.restype = C.c_uint32
+    L.dnagpu_records_offsets.argtypes = [vp, u64p]
+    L.dnagpu_records_device.argtypes = [vp]
+    L.dnagpu_records_device.restype = vp
+    L.dnagpu_records_free.argtypes = [vp, vp]
+    L.dnagpu_records_free.restype = None
+    L.dnagpu_count_records.argtypes = [vp, C.POINTER(vp), u64p, C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.c_uint64,
+                                       C.POINTER(vp)]
     L.dnagpu_count_keys.argtypes = [vp, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.dnagpu_count_kmers_owned.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
     L.dnagpu_count_keys_in_range.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
@@ -209,6 +220,23 @@ class Dna:
     def free(self):
         if self.h:
             lib().dnagpu_dna_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Records:
+    """dnagpu_records: 16-byte super-k-mer records in device memory, grouped by coarse bucket"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        self.n_buckets = int(lib().dnagpu_records_buckets(h))
+        self.offsets = np.zeros(self.n_buckets + 1, dtype=np.uint64)
+        _chk(lib().dnagpu_records_offsets(h, self.offsets.ctypes.data_as(u64p)))
+        self.device_ptr = lib().dnagpu_records_device(h)
+        self.n_records = int(self.offsets[-1])
+
+    def free(self):
+        if self.h:
+            lib().dnagpu_records_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -423,6 +451,27 @@ class Context:
             count = max(total - first, 0)
         h = C.c_void_p()
         _chk(lib().dnagpu_count_kmers_unordered(self.h, dna.h, k, first, count, C.byref(h)))
+        return Hist(self, h)
+
+    # ---- the unordered count in two halves (rows on several GPUs: sharded.count_sharded_exchange_records)
+    def sk_buckets(self, global_rows, k):
+        return int(lib().dnagpu_sk_buckets(self.h, global_rows, k))
+
+    def sk_records(self, dna, k, first, count, global_rows):
+        """super-k-mer records of rows [first, first+count), grouped by coarse bucket -> Records"""
+        r = C.c_void_p()
+        _chk(lib().dnagpu_sk_records(self.h, dna.h, k, first, count, global_rows, C.byref(r)))
+        return Records(self, r)
+
+    def count_records(self, pieces, k, global_rows):
+        """pieces: [(device pointer, n_records, bucket)] -> Hist (unordered) of the k-mers in them"""
+        n = len(pieces)
+        ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(int(p[0])) for p in pieces])
+        lens = np.asarray([int(p[1]) for p in pieces], dtype=np.uint64)
+        bks = np.asarray([int(p[2]) for p in pieces], dtype=np.uint32)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_records(self.h, ptrs, lens.ctypes.data_as(u64p), bks.ctypes.data_as(C.POINTER(C.c_uint32)), n, k,
+                                        global_rows, C.byref(h)))
         return Hist(self, h)
 
     def count_kmers_owned(self, dna, k, owner, n_owners, first=0, count=None):

@@ -1280,30 +1280,45 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
 // Heavy mid buckets (more than SK_MID_LIMIT k-mers: the minimizers of repeats) are taken out of the record path: their
 // nodes come back in *heavy (device copies, start / len in records of *heavy_recs), their k-mer counts in heavy_kc.
 struct SkHeavy {
-    Node *nodes = nullptr;      // device, n entries: start / len in records, child_base = k-mers
+    Node *nodes = nullptr;      // device, n entries: start / len in records, child_base = k-mers (if counted)
     u32 n = 0;
+    bool counted = true;        // child_base holds the bucket's k-mers (checked against its expansion)
     void *recs = nullptr;       // the record buffer they live in
     u64 total = 0;              // k-mers of all
 };
-static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, void **recs,
-                        Node **fin, u32 *n_fin, SkHeavy *heavy)
+// geometry of a count of n rows: final buckets of ~SK_LEAF_MEAN k-mers = 16 per mid bucket; mid buckets = c0n coarse x 2^b1.
+// A multi-GPU count derives it from the GLOBAL row count on every rank (the digits are part of the records).
+struct SkGeom {
+    int b1, r0bits;
+    u32 c0n;
+    u64 mid_limit;
+};
+static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n)
 {
-
-    hipStream_t st = ctx->stream;
-    // geometry: final buckets of ~SK_LEAF_MEAN k-mers = 16 per mid bucket; mid buckets = C0 coarse x 2^b1
+    SkGeom g;
     const u64 n_final = std::max<u64>(n / SK_LEAF_MEAN, 16);
     const u64 n_mid = (n_final + 15) / 16;
-    int b1 = 1;
-    while (b1 < MAX_SPLIT_BITS && ((u64)1 << b1) < n_mid)
-        b1++;
-    const u32 c0n = (u32)std::min<u64>((n_mid + ((u64)1 << b1) - 1) >> b1, (u64)sk_max_c0());
-    int r0bits = 1;
-    while ((1u << r0bits) < c0n)
-        r0bits++;
+    g.b1 = 1;
+    while (g.b1 < MAX_SPLIT_BITS && ((u64)1 << g.b1) < n_mid)
+        g.b1++;
+    g.c0n = (u32)std::min<u64>((n_mid + ((u64)1 << g.b1) - 1) >> g.b1, (u64)sk_max_c0());
+    g.r0bits = 1;
+    while ((1u << g.r0bits) < g.c0n)
+        g.r0bits++;
     // (the forced engine of the tests calls a bucket heavy at three times the mean, so that short sequences take that path too)
-    const u64 mid_limit = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) ? 3 * (n / ((u64)c0n << b1) + 1) : SK_MID_LIMIT;
+    g.mid_limit = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) ? 3 * (n / ((u64)g.c0n << g.b1) + 1) : SK_MID_LIMIT;
+    return g;
+}
 
-    // ---- level 0: the packed sequence -> records in c0n coarse buckets
+// Level 0: rows [first, first + n) of the packed sequence -> records in the coarse buckets of geometry g.
+// *rec0 = the record buffer (pool memory of ps), *coarse / *n_coarse = the 2^r0bits coarse nodes (device; start / len in
+// records, in digit order), kids = the same on the host.
+static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, const SkGeom &g, void **rec0_out,
+                     Node **coarse, u32 *n_coarse, std::vector<Node> *kids_out, u64 *n_recs_out)
+{
+    hipStream_t st = ctx->stream;
+    const int b1 = g.b1, r0bits = g.r0bits;
+    const u32 c0n = g.c0n;
     Node root;
     memset(&root, 0, sizeof root);
     root.len = (u32)n;
@@ -1324,7 +1339,8 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     prof_mark(ctx, "sk_prefix0");
     HIP_TRY(launch_level_prefix(cur, l0.chunks, l0.n_chunks, 1, (u32)chunk_rows, l0.hist, l0.tot, st));
     HIP_TRY(launch_level_children(cur, 1, l0.tot, l0.next, nullptr, nullptr, nullptr, 0, st));
-    std::vector<Node> kids(l0.n_next);
+    std::vector<Node> &kids = *kids_out;
+    kids.resize(l0.n_next);
     HIP_TRY(hipMemcpyAsync(kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     u64 n_recs = 0;
@@ -1332,12 +1348,31 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
         n_recs += c.len;
     if (n_recs > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
-    void *rec0 = nullptr, *rec1 = nullptr;
+    void *rec0 = nullptr;
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec0));
     ps.ptrs.push_back(rec0);
     prof_mark(ctx, "sk_scatter0");
     HIP_TRY(launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
                              l0.hist, l0.tot, rec0, st));
+    *rec0_out = rec0;
+    *coarse = l0.next;
+    *n_coarse = l0.n_next;
+    *n_recs_out = n_recs;
+    return DNAGPU_OK;
+}
+
+// Levels 1 and 2 over coarse nodes (records of rec0, which this takes over).  n = the k-mers the records must hold
+// (0 = not known: records received from other ranks).  On success *n_kmers = the k-mers found.
+static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *coarse, u32 n_coarse, void *rec0, u64 n_recs, u64 n,
+                       void **recs, Node **fin, u32 *n_fin, SkHeavy *heavy, u64 *n_kmers)
+{
+    hipStream_t st = ctx->stream;
+    const int b1 = g.b1;
+    const u64 mid_limit = g.mid_limit;
+    void *rec1 = nullptr;
+    SkLevel l0;                                  // (only the node list of level 0 is used below)
+    l0.next = coarse;
+    l0.n_next = n_coarse;
 
     // ---- level 1: records of every coarse bucket -> 2^b1 mid buckets; k-mers per mid bucket on the way
     u64 chunk_recs = std::max<u64>(4 * 8192, (n_recs + 4095) / 4096);
@@ -1351,7 +1386,7 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
     prof_mark(ctx, "sk_hist1");
     HIP_TRY(launch_sk_hist1(l0.next, l1.chunks, l1.n_chunks, rec0, l1.hist, kcount, st));
     prof_mark(ctx, "sk_prefix1");
-    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, c0n, (u32)chunk_recs, l1.hist, l1.tot, st));
+    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st));
     HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
     // ---- skew check on the k-mers per mid bucket, before their records move (the list is short: host)
     std::vector<u32> kc(l1.n_next);
@@ -1362,10 +1397,13 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
         run += kc[i];
         heaviest = std::max<u64>(heaviest, kc[i]);
     }
-    if (run != n) {
+    if (n != 0 && run != n) {
         set_err("super-k-mer partition lost rows: %llu of %llu", (unsigned long long)run, (unsigned long long)n);
         return DNAGPU_ERR_INTERNAL;
     }
+    if (run > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    *n_kmers = run;
     std::vector<u32> heavy_idx;
     if (heaviest > mid_limit) {
         for (u32 i = 0; i < l1.n_next; i++)
@@ -1375,7 +1413,7 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
             }
         // a sequence that is mostly repeats (poly-A, satellites over more than half of it) is cheaper through the tree
         // from scratch
-        if (heavy->total * 2 > n || heavy_idx.size() > 4096)
+        if (heavy->total * 2 > run || heavy_idx.size() > 4096)
             return DNAGPU_SK_SKEWED;
     }
 
@@ -1411,15 +1449,97 @@ static int sk_partition(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u
 
 // The whole count: partition, then final buckets of at most sk_count_cap() k-mers are counted from their records
 // (sk_count), the others expanded to keys and counted by the ordinary levels.  Fills h on success.
+static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, u32 n_fin, const SkHeavy &heavy, u64 n, int k,
+                         dnagpu_hist *h);
+
 static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, dnagpu_hist *h)
+{
+    PoolScope ps(ctx);
+    const SkGeom g = sk_geometry(ctx, n);
+    void *rec0 = nullptr, *recs = nullptr;
+    Node *coarse = nullptr, *fin = nullptr;
+    u32 n_coarse = 0, n_fin = 0;
+    u64 n_recs = 0, n_kmers = 0;
+    std::vector<Node> kids;
+    SkHeavy heavy;
+    RC_TRY(sk_level0(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs));
+    RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n, &recs, &fin, &n_fin, &heavy, &n_kmers));
+    return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n, k, h);
+}
+
+// Records that arrive from elsewhere (the multi-GPU exchange: every rank cuts the records of its own chunk and ships each
+// coarse bucket to its owner): pieces[i] = piece_len[i] records of coarse bucket piece_bucket[i], device memory.  The
+// pieces are copied bucket by bucket into one buffer (equal k-mers share the bucket, so its pieces must form ONE node),
+// then levels 1-2 and the counting as in count_sk.  A skewed set (more than half the k-mers in heavy mid buckets)
+// cannot fall back to the sequence here: all of it is expanded to keys for the ordinary levels instead.
+static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u64 *piece_len, const u32 *piece_bucket, u32 n_pieces,
+                            int k, u64 global_rows, dnagpu_hist *h)
 {
     hipStream_t st = ctx->stream;
     PoolScope ps(ctx);
+    const SkGeom g = sk_geometry(ctx, global_rows);
+    const u32 n_coarse = 1u << g.r0bits;
+    std::vector<u64> blen(n_coarse, 0), boff(n_coarse + 1, 0);
+    for (u32 i = 0; i < n_pieces; i++) {
+        if (piece_bucket[i] >= g.c0n || (piece_len[i] && !pieces[i]))
+            return DNAGPU_ERR_BAD_ARG;
+        blen[piece_bucket[i]] += piece_len[i];
+    }
+    for (u32 d = 0; d < n_coarse; d++)
+        boff[d + 1] = boff[d] + blen[d];
+    const u64 n_recs = boff[n_coarse];
+    if (n_recs > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    if (n_recs == 0) {
+        h->total = 0;
+        return DNAGPU_OK;
+    }
+    void *rec0 = nullptr;
+    RC_TRY(pool_alloc(ctx, (size_t)n_recs * 16, &rec0));
+    ps.ptrs.push_back(rec0);
+    std::vector<u64> fill(boff.begin(), boff.end() - 1);
+    for (u32 i = 0; i < n_pieces; i++)
+        if (piece_len[i]) {
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(rec0) + fill[piece_bucket[i]] * 16, pieces[i], (size_t)piece_len[i] * 16,
+                                   hipMemcpyDeviceToDevice, st));
+            fill[piece_bucket[i]] += piece_len[i];
+        }
+    std::vector<Node> hn(n_coarse);
+    for (u32 d = 0; d < n_coarse; d++) {
+        memset(&hn[d], 0, sizeof(Node));
+        hn[d].start = (u32)boff[d];
+        hn[d].len = (u32)blen[d];
+        hn[d].meta = (u32)(32 - g.r0bits);       // (what level_children leaves a child of the 32-"bit" root)
+    }
+    Node *coarse = nullptr;
+    RC_TRY(ps.alloc((size_t)n_coarse, &coarse));
+    HIP_TRY(hipMemcpyAsync(coarse, hn.data(), (size_t)n_coarse * sizeof(Node), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));           // (hn, and the caller's pieces, are free again)
     void *recs = nullptr;
     Node *fin = nullptr;
     u32 n_fin = 0;
+    u64 n_kmers = 0;
     SkHeavy heavy;
-    RC_TRY(sk_partition(ctx, ps, dna, first, n, k, &recs, &fin, &n_fin, &heavy));
+    int rc = sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, 0, &recs, &fin, &n_fin, &heavy, &n_kmers);
+    if (rc == DNAGPU_SK_SKEWED) {
+        // every coarse bucket as one "heavy" bucket: keys, then the ordinary levels (sk_levels12 has not moved anything yet)
+        heavy = SkHeavy();
+        heavy.nodes = coarse;
+        heavy.n = n_coarse;
+        heavy.recs = rec0;
+        heavy.total = n_kmers;
+        heavy.counted = false;
+        n_fin = 0;
+        rc = DNAGPU_OK;
+    }
+    RC_TRY(rc);
+    return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n_kmers, k, h);
+}
+
+static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, u32 n_fin, const SkHeavy &heavy, u64 n, int k,
+                         dnagpu_hist *h)
+{
+    hipStream_t st = ctx->stream;
     const u32 n_heavy = heavy.n;
     prof_mark(ctx, "sk_select");
     const u32 cap = (u32)sk_count_cap();
@@ -1495,8 +1615,8 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
             HIP_TRY(launch_sk_slice_kmers(rbuf, d_r0, d_nr, n_slices, d_ko, st));
             HIP_TRY(launch_scan_u32(d_ko, d_ko, n_slices, ktmp, stot + 1, st));
             const u32 key_base = part == 0 ? 0u : (u32)over_keys;
-            HIP_TRY(launch_sk_slice_nodes(bk, nb, sfirst, d_ko, n_slices, stot + 1, key_base, k, true, knodes + (part == 0 ? 0 : n_over),
-                                          cursor + 1, st));
+            HIP_TRY(launch_sk_slice_nodes(bk, nb, sfirst, d_ko, n_slices, stot + 1, key_base, k, part == 0 || heavy.counted,
+                                          knodes + (part == 0 ? 0 : n_over), cursor + 1, st));
             HIP_TRY(launch_sk_expand_flat(rbuf, d_r0, d_nr, d_ko, key_base, n_slices, k, kbuf, st));
         }
         RC_TRY(run_tree(ctx, ps, nullptr, 0, tree_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes, n_tree, 2));
@@ -1752,6 +1872,107 @@ extern "C" int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *d
 }
 
 extern "C" int dnagpu_hist_is_sorted(const dnagpu_hist *h) { return h && h->sorted ? 1 : 0; }
+
+// ---- the two halves of the unordered count, for a count whose rows live on several GPUs: records of a rank's own rows,
+// grouped by coarse bucket (to be shipped to the buckets' owners), and the count of the records a rank has received
+struct dnagpu_records {
+    void *recs;                 // pool memory: 16 bytes per record, bucket after bucket
+    std::vector<u64> off;       // n_buckets + 1 offsets (records)
+};
+
+extern "C" int dnagpu_sk_buckets(const dnagpu_ctx *ctx, uint64_t global_rows, int k)
+{
+    if (!ctx || k < sk_min_k() || k > 32 || global_rows == 0 || global_rows > 0xFFFFFFFFull)
+        return 0;
+    return (int)sk_geometry(ctx, global_rows).c0n;
+}
+
+extern "C" int dnagpu_sk_records(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first, uint64_t count,
+                                 uint64_t global_rows, dnagpu_records **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || !out || k < sk_min_k() || k > 32 || global_rows < count || global_rows == 0 || global_rows > 0xFFFFFFFFull)
+        return DNAGPU_ERR_BAD_ARG;
+    RC_TRY(check_range(dna, k, first, count));
+    HIP_TRY(hipSetDevice(ctx->device));
+    const SkGeom g = sk_geometry(ctx, global_rows);
+    dnagpu_records *r = new (std::nothrow) dnagpu_records();
+    if (!r)
+        return DNAGPU_ERR_OOM;
+    r->recs = nullptr;
+    r->off.assign((size_t)g.c0n + 1, 0);
+    if (count > 0) {
+        PoolScope ps(ctx);
+        void *rec0 = nullptr;
+        Node *coarse = nullptr;
+        u32 n_coarse = 0;
+        u64 n_recs = 0;
+        std::vector<Node> kids;
+        prof_begin(ctx);
+        const int rc = sk_level0(ctx, ps, dna, first, count, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs);
+        prof_end(ctx);
+        if (rc != DNAGPU_OK) {
+            delete r;
+            return rc;
+        }
+        for (u32 d = 0; d < g.c0n; d++)
+            r->off[d + 1] = r->off[d] + (d < kids.size() ? kids[d].len : 0);
+        const hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (r->off[g.c0n] != n_recs || se != hipSuccess) {
+            set_err("super-k-mer level 0: %llu records in the buckets, %llu counted (%s)", (unsigned long long)r->off[g.c0n],
+                    (unsigned long long)n_recs, hipGetErrorString(se));
+            delete r;
+            return se != hipSuccess ? DNAGPU_ERR_HIP : DNAGPU_ERR_INTERNAL;
+        }
+        ps.release(rec0);
+        r->recs = rec0;
+    }
+    *out = r;
+    return DNAGPU_OK;
+    });
+}
+
+extern "C" uint32_t dnagpu_records_buckets(const dnagpu_records *r) { return r ? (uint32_t)(r->off.size() - 1) : 0; }
+extern "C" int dnagpu_records_offsets(const dnagpu_records *r, uint64_t *offsets)
+{
+    if (!r || !offsets)
+        return DNAGPU_ERR_BAD_ARG;
+    for (size_t i = 0; i < r->off.size(); i++)
+        offsets[i] = r->off[i];
+    return DNAGPU_OK;
+}
+extern "C" void *dnagpu_records_device(const dnagpu_records *r) { return r ? r->recs : nullptr; }
+extern "C" void dnagpu_records_free(dnagpu_ctx *ctx, dnagpu_records *r)
+{
+    if (!r)
+        return;
+    if (ctx)
+        pool_free(ctx, r->recs);
+    delete r;
+}
+
+extern "C" int dnagpu_count_records(dnagpu_ctx *ctx, const void *const *pieces, const uint64_t *piece_len,
+                                    const uint32_t *piece_bucket, uint32_t n_pieces, int k, uint64_t global_rows, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !out || (n_pieces && (!pieces || !piece_len || !piece_bucket)) || k < sk_min_k() || k > 32 || global_rows == 0 ||
+        global_rows > 0xFFFFFFFFull)
+        return DNAGPU_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, false};
+    if (!h)
+        return DNAGPU_ERR_OOM;
+    prof_begin(ctx);
+    const int rc = count_sk_records(ctx, pieces, piece_len, piece_bucket, n_pieces, k, global_rows, h);
+    prof_end(ctx);
+    if (rc != DNAGPU_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return DNAGPU_OK;
+    });
+}
 
 extern "C" int dnagpu_count_kmers_owned(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first,
                                         uint64_t count, int owner, int n_owners, dnagpu_hist **out)

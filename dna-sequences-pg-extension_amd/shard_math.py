@@ -43,3 +43,14 @@ def shard_ranges(n_bases, k, world):
         base_hi = min(hi + k - 1, n_bases) if hi > lo else base_lo
         out.append((lo, hi - lo, base_lo, base_hi))
     return out
+
+
+def bucket_owner_ranges(n_buckets, world):
+    """Coarse buckets of the record exchange per owner: owner o holds buckets [lo, hi) with (b * world) // n_buckets == o
+    (contiguous, so a rank's records, which are grouped by bucket, are already grouped by owner)."""
+    out = []
+    for o in range(world):
+        lo = (o * n_buckets + world - 1) // world
+        hi = ((o + 1) * n_buckets + world - 1) // world
+        out.append((lo, max(hi, lo)))
+    return out

@@ -26,7 +26,7 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from .shard_math import OWNER_BITS, owner_key_range, shard_ranges, word_chunks  # noqa: F401  (pure arithmetic: no torch)
+from .shard_math import OWNER_BITS, bucket_owner_ranges, owner_key_range, shard_ranges, word_chunks  # noqa: F401  (pure arithmetic: no torch)
 
 
 class _DevArray:
@@ -99,6 +99,28 @@ class GpuEngine:
     def free_dna(self, dna):
         dna.free()
 
+    # ---- record-exchange variant
+    def sk_buckets(self, global_rows, k):
+        return self.ctx.sk_buckets(global_rows, k)
+
+    def sk_records(self, dna, k, count, global_rows):
+        """-> (int64 tensor view of the records, two words each, grouped by bucket; offsets per bucket in records)"""
+        r = self.ctx.sk_records(dna, k, 0, count, global_rows)
+        self._records = r
+        if r.n_records == 0:
+            return self.empty(0), [0] * (r.n_buckets + 1)
+        return torch.as_tensor(_DevArray(r.device_ptr, 2 * r.n_records), device=self.device), [int(x) for x in r.offsets]
+
+    def count_records(self, recv_t, pieces, k, global_rows):
+        """pieces: [(offset in records inside recv_t, n_records, bucket)]"""
+        torch.cuda.synchronize(self.device)
+        base = recv_t.data_ptr() if recv_t.numel() else 0
+        hist = self.ctx.count_records([(base + 16 * off, n, b) for off, n, b in pieces if n], k, global_rows)
+        if getattr(self, "_records", None) is not None:
+            self._records.free()
+            self._records = None
+        return hist
+
 
 def gather_sequence(chunk_t, world, engine, always=False):
     """All-gather of the packed chunks -> the whole packed sequence on every rank.
@@ -161,4 +183,41 @@ def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None,
     key_min, key_max = owner_key_range(k, rank, world)
     hist = engine.count_keys(recv, k, key_min, key_max)
     engine.release()
+    return hist, dna
+
+
+def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False):
+    """The record-exchange variant (k >= 23): rank r cuts the super-k-mer records of its OWN rows only, every coarse
+    bucket goes to its owner with one all-to-all (1.8 bytes per k-mer at k = 31; nothing is swept twice and no rank
+    touches the whole sequence), and the owner counts the records it received.  The ranks' histograms are disjoint
+    (a k-mer's bucket depends on its content alone) but in no key order.  Returns (hist, dna) like count_sharded."""
+    first, n_mine, base_lo, base_hi = shard_ranges(n_bases, k, world)[rank]
+    global_rows = max(n_bases - k + 1, 0)
+    if dna is None:
+        dna = engine.make_shard(seed, base_lo, base_hi)
+    n_buckets = engine.sk_buckets(global_rows, k)
+    owners = bucket_owner_ranges(n_buckets, world)
+    send, boffs = engine.sk_records(dna, k, n_mine, global_rows)        # records grouped by bucket = by owner
+    # what every rank holds of every bucket: the receiver needs the piece boundaries inside what it is sent
+    via_host = dist.get_backend() == "gloo"
+    counts = torch.tensor([boffs[b + 1] - boffs[b] for b in range(n_buckets)], dtype=torch.int64,
+                          device="cpu" if via_host or not send.is_cuda else send.device)
+    all_counts = torch.empty(world * n_buckets, dtype=torch.int64, device=counts.device)
+    if world == 1 and not always_collective:
+        all_counts.copy_(counts)
+    else:
+        dist.all_gather_into_tensor(all_counts, counts)
+    all_counts = all_counts.cpu().view(world, n_buckets)
+    offsets = [2 * boffs[owners[o][0]] if owners[o][0] < n_buckets else 2 * boffs[n_buckets] for o in range(world)]
+    offsets.append(2 * boffs[n_buckets])                                # (int64 words: two per record)
+    recv = exchange(send, offsets, world, engine, always_collective)
+    lo, hi = owners[rank]
+    pieces, pos = [], 0
+    for src in range(world):                                            # the all-to-all delivers source after source
+        for b in range(lo, hi):
+            n = int(all_counts[src, b])
+            pieces.append((pos, n, b))
+            pos += n
+    assert 2 * pos == recv.numel(), (pos, recv.numel())
+    hist = engine.count_records(recv, pieces, k, global_rows)
     return hist, dna

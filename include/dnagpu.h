@@ -237,6 +237,35 @@ void dnagpu_buffer_free(dnagpu_ctx *ctx, void *dev_ptr);
 int dnagpu_buffer_download(dnagpu_ctx *ctx, const void *dev_ptr, uint64_t bytes, void *host);
 int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint64_t bytes);
 
+/* ---- the unordered count in two halves, for rows that live on several GPUs (the real exchange step
+ * of the sharded path; dna-sequences-pg-extension_amd/sharded.py: count_sharded_exchange_records) -------------------
+ * The super-k-mer engine (dnagpu_count_kmers_unordered) cuts the rows into 16-byte RECORDS -- runs of consecutive
+ * k-mers that share their minimizer, ~9 k-mers each at k = 31 -- and sends every record to a coarse bucket that
+ * depends on the k-mers' content alone.  A rank therefore cuts only its OWN rows (dnagpu_sk_records), ships every
+ * bucket to its owner (1.8 bytes per k-mer instead of 8; the caller's all-to-all), and counts what it receives
+ * (dnagpu_count_records): equal k-mers meet because they share the bucket.  global_rows = the rows of the whole
+ * count: every rank must pass the same value (it fixes the bucket geometry, and the digits are part of the
+ * records).  k in [23, 32]. */
+typedef struct dnagpu_records dnagpu_records;
+/* number of coarse buckets of a count of global_rows rows (0: arguments out of range) */
+int dnagpu_sk_buckets(const dnagpu_ctx *ctx, uint64_t global_rows, int k);
+/* records of rows [first, first+count) of generate_kmers(dna, k), grouped by bucket in device memory */
+int dnagpu_sk_records(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first, uint64_t count,
+                      uint64_t global_rows, dnagpu_records **out);
+uint32_t dnagpu_records_buckets(const dnagpu_records *r);
+/* offsets[b] .. offsets[b+1] = bucket b's records (dnagpu_records_buckets(r) + 1 entries, host memory) */
+int dnagpu_records_offsets(const dnagpu_records *r, uint64_t *offsets);
+void *dnagpu_records_device(const dnagpu_records *r);      /* 16 bytes per record; pooled (stream rule above) */
+void dnagpu_records_free(dnagpu_ctx *ctx, dnagpu_records *r);
+/* GROUP BY kmer, count(*) over the k-mers of the given records: pieces[i] = piece_len[i] records of bucket
+ * piece_bucket[i] in device memory (any order, several pieces per bucket allowed: one per sending rank); every
+ * record of a bucket that exists anywhere must be among them, or equal k-mers are counted apart.  The histogram is
+ * unordered (dnagpu_hist_is_sorted == 0); dnagpu_hist_total = the k-mers the records held.  The pieces are copied
+ * before the call returns. */
+int dnagpu_count_records(dnagpu_ctx *ctx, const void *const *pieces, const uint64_t *piece_len,
+                         const uint32_t *piece_bucket, uint32_t n_pieces, int k, uint64_t global_rows,
+                         dnagpu_hist **out);
+
 /* ---- multi-GPU count from one process (the call a PostgreSQL backend's glue makes; SURVEY.md 8(b)
  * dnagpu_count_multi) ----------------------------------------------------------------------------------
  * A dnagpu_multi holds one context per rank (rank r on HIP device devices[r]; devices == NULL means 0..n-1;

@@ -82,6 +82,34 @@ class OracleEngine:
     def free_dna(self, dna):
         pass
 
+    # ---- record-exchange variant: a "record" here is (key, 1) and the bucket a hash of the key -- the host logic under
+    # test (owner ranges, split sizes, piece boundaries) sees 16-byte records grouped by bucket, as from the GPU engine
+    N_BUCKETS = 7
+
+    def sk_buckets(self, global_rows, k):
+        return self.N_BUCKETS
+
+    def sk_records(self, dna, k, count, global_rows):
+        words, n = dna
+        keys = orc.generate_kmers(words, n, k, 0, count, faithful=False)
+        bucket = ((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(self.N_BUCKETS)
+        order = np.argsort(bucket, kind="stable")
+        offs = [int(x) for x in np.searchsorted(bucket[order], np.arange(self.N_BUCKETS + 1))]
+        recs = np.empty(2 * len(keys), dtype=np.uint64)
+        recs[0::2] = keys[order]
+        recs[1::2] = 1
+        return torch.from_numpy(recs.view(np.int64).copy()), offs
+
+    def count_records(self, recv_t, pieces, k, global_rows):
+        recs = recv_t.numpy().view(np.uint64)
+        assert sum(n for _, n, _ in pieces) * 2 == recs.size
+        keys = recs[0::2]
+        for off, n, b in pieces:                   # every piece holds records of the bucket it is said to hold
+            kk = keys[off:off + n]
+            assert np.all(((kk * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(self.N_BUCKETS) == b)
+        k_, c_ = orc.count_keys(keys)
+        return OracleHist(k_, c_)
+
 
 def main():
     engine_name, n_bases, k, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
@@ -104,6 +132,8 @@ def main():
         engine = OracleEngine()
     if mode == "gather":
         hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world, always_collective=True)
+    elif mode == "records":
+        hist, dna = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, always_collective=True)
     else:
         hist, dna = sh.count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, always_collective=True)
     keys, counts = hist.download()
@@ -112,6 +142,9 @@ def main():
     if rank == 0:
         gk = np.concatenate([p[0] for p in parts])
         gc = np.concatenate([p[1] for p in parts])
+        if mode == "records":                      # unordered by construction: the ranks' groups are disjoint, in no key order
+            order = np.argsort(gk, kind="stable")
+            gk, gc = gk[order], gc[order]
         words = orc.synth_words(seed, n_bases)
         ok, oc = orc.count_kmers(words, n_bases, k)
         res = {"ok": bool(np.array_equal(gk, ok) and np.array_equal(gc, oc)),

@@ -803,6 +803,54 @@ def test_count_kmers_owned(ctx, n_owners):
         d.free()
 
 
+# ------------------------------------------------------------------ the unordered count in two halves (record exchange)
+
+@pytest.mark.parametrize("world,n,k,motif", [(1, 3_000_000, 31, 0), (2, 3_000_017, 31, 0), (3, 2_000_003, 27, 0), (8, 5_000_000, 29, 0),
+                                             (2, 100_000, 23, 0), (4, 1_000, 32, 0), (2, 4_000_000, 31, 1000), (3, 3_000_000, 31, 7),
+                                             (2, 2_000_000, 25, 1)])
+def test_records_exchange_one_process(ctx, pkg, world, n, k, motif):
+    """dnagpu_sk_records + dnagpu_count_records, the exchange done by hand in one process: every "rank" cuts the records
+    of its own rows (its shard + the k-1 base halo, the global row count fixing the bucket geometry), every owner counts
+    the pieces of its buckets from all ranks; the owners' groups are disjoint and together the oracle's histogram.
+    motif > 0: repeat-rich input (heavy buckets; more than half the k-mers heavy: everything is expanded to keys)."""
+    import importlib
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
+    seed = 0xD2A0003 + n
+    words = orc.synth_words_repeat(seed, n, motif) if motif else orc.synth_words(seed, n)
+    ok, oc = orc.count_kmers(words, n, k)
+    rows = n - k + 1
+    n_buckets = ctx.sk_buckets(rows, k)
+    assert n_buckets >= 1
+    recs = []
+    for first, cnt, lo, hi in sh.shard_ranges(n, k, world):
+        w = np.ascontiguousarray(words[lo // 32:(hi + 31) // 32]) if hi > lo else np.zeros(0, dtype=np.uint64)
+        d = ctx.upload(w, hi - lo)
+        r = ctx.sk_records(d, k, 0, cnt, rows)
+        assert r.n_buckets == n_buckets and int(r.offsets[0]) == 0 and np.all(np.diff(r.offsets.astype(np.int64)) >= 0)
+        d.free()
+        recs.append(r)
+    gk, gc, total = [], [], 0
+    for lo_b, hi_b in sh.bucket_owner_ranges(n_buckets, world):
+        pieces = [(r.device_ptr + 16 * int(r.offsets[b]), int(r.offsets[b + 1] - r.offsets[b]), b)
+                  for r in recs for b in range(lo_b, hi_b) if r.n_records]
+        h = ctx.count_records(pieces, k, rows)
+        assert not h.is_sorted or h.distinct == 0
+        a, c = h.download()
+        gk.append(a)
+        gc.append(c)
+        total += h.total
+        h.free()
+    for r in recs:
+        r.free()
+    gk, gc = np.concatenate(gk), np.concatenate(gc)
+    order = np.argsort(gk, kind="stable")
+    assert total == rows
+    assert_same(gk[order], ok, f"records exchange world={world} keys")
+    assert_same(gc[order], oc, f"records exchange world={world} counts")
+    with pytest.raises(pkg.DnaGpuError):
+        ctx.count_records([(0, 5, n_buckets)], k, rows)          # a bucket the geometry does not have
+
+
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])

@@ -68,6 +68,41 @@ def test_sharded_count_gloo_oracle_engine(tmp_path, world, n_bases, k, mode):
     assert res["ok"] and res["sorted"], res
 
 
+def test_bucket_owner_ranges_cover_exactly_once():
+    pkg = load_package()
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
+    for nb, w in [(64, 8), (56, 8), (7, 2), (7, 3), (1, 4), (128, 6), (3, 8)]:
+        r = sh.bucket_owner_ranges(nb, w)
+        assert r[0][0] == 0 and r[-1][1] == nb
+        for (lo, hi), (lo2, _) in zip(r, r[1:]):
+            assert lo <= hi == lo2
+        for b in range(nb):
+            o = (b * w) // nb
+            assert r[o][0] <= b < r[o][1]
+
+
+@pytest.mark.parametrize("world,n_bases,k", [(2, 200_000, 31), (3, 100_001, 25), (2, 5000, 23)])
+def test_sharded_records_gloo_oracle_engine(tmp_path, world, n_bases, k):
+    """the record exchange's host logic (bucket owners, split sizes, piece boundaries) with the oracle standing in"""
+    res = run_world("oracle", world, n_bases, k, tmp_path, 0, "records")
+    assert res["ok"] and res["sorted"], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 27), (2, 70_000, 23), (1, 6_000_000, 31)])
+def test_sharded_records_gloo_gpu_engine(tmp_path, world, n_bases, k):
+    """count_sharded_exchange_records with the product engine: every rank cuts the records of its own rows
+    (dnagpu_sk_records), the buckets travel to their owners, the owners count them (dnagpu_count_records)"""
+    res = run_world("gpu", world, n_bases, k, tmp_path, 0, "records")
+    assert res["ok"] and res["sorted"], res
+
+
+@pytest.mark.gpu
+def test_sharded_records_rccl_one_rank(tmp_path):
+    res = run_world("gpu", 1, 2_000_000, 31, tmp_path, 0, "records", backend="nccl")
+    assert res["ok"] and res["sorted"], res
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["gather", "keys"])
 @pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 21), (2, 70_000, 4)])
