@@ -174,11 +174,19 @@ def main():
         sh = importlib.import_module(pkg.__name__ + ".sharded")
         engine = sh.GpuEngine(pkg, ctx, torch.device("cuda", local_rank))
         state = {"chunk": None}
+        # long k-mers, any group order (the single-GPU default's rule): every rank cuts the super-k-mer records of its own
+        # rows, the coarse buckets travel to their owners (one all-to-all of 1.8 B per k-mer), the owners count them
+        use_records = args.engine != "tree" and k >= 29
+        extra["exchange"] = ("records: own rows -> super-k-mer records -> all-to-all by coarse bucket -> count" if use_records else
+                             "sequence: all-gather of the packed chunks -> every rank counts the key range it owns")
 
         def step():
-            # resident input = this rank's word chunk of the packed sequence; the step all-gathers
-            # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
-            h, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
+            if use_records:
+                h, state["chunk"] = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, state["chunk"])
+            else:
+                # resident input = this rank's word chunk of the packed sequence; the step all-gathers
+                # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
+                h, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
             distinct[0] = h.distinct
             for name, ms in ctx.last_phase_times():
                 phases_acc.setdefault(name, []).append(ms)
@@ -278,7 +286,7 @@ def main():
             eng = "" if world > 1 else (", ordered groups (MSD radix tree)" if sorted_result[0] else ", unordered groups (super-k-mer partitioning)")
             workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}"
                         f"{', motif ' + str(args.motif) if args.motif else ''}){eng}, "
-                        f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, all-gather of the packed sequence + owner-filtered count'}")
+                        f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, ' + extra.get('exchange', '')}")
             unit = "k-mers/s"
         line = {
             "metric": metric,

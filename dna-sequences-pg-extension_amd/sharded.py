@@ -208,10 +208,20 @@ def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=No
     else:
         dist.all_gather_into_tensor(all_counts, counts)
     all_counts = all_counts.cpu().view(world, n_buckets)
-    offsets = [2 * boffs[owners[o][0]] if owners[o][0] < n_buckets else 2 * boffs[n_buckets] for o in range(world)]
-    offsets.append(2 * boffs[n_buckets])                                # (int64 words: two per record)
-    recv = exchange(send, offsets, world, engine, always_collective)
     lo, hi = owners[rank]
+    # split sizes in int64 words (two per record); what arrives is known from the counts: no size exchange
+    in_splits = [2 * (boffs[min(owners[o][1], n_buckets)] - boffs[min(owners[o][0], n_buckets)]) for o in range(world)]
+    out_splits = [2 * int(all_counts[src, lo:hi].sum()) for src in range(world)]
+    if world == 1 and not always_collective:
+        recv = send
+    elif via_host and send.is_cuda:                                     # gloo has no device all-to-all (test rig)
+        recv_h = torch.empty(sum(out_splits), dtype=torch.int64)
+        dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits)
+        recv = engine.empty(sum(out_splits))
+        recv.copy_(recv_h)
+    else:
+        recv = engine.empty(sum(out_splits))
+        dist.all_to_all_single(recv, send, out_splits, in_splits)
     pieces, pos = [], 0
     for src in range(world):                                            # the all-to-all delivers source after source
         for b in range(lo, hi):

@@ -1,0 +1,66 @@
+"""Per-rank critical path of the record exchange on one GPU (no collective): for W ranks, the time of one rank's level 0
+over its own rows (dnagpu_sk_records) and of one owner's count over the pieces all W ranks would send it
+(dnagpu_count_records), plus the bytes that rank sends / receives.
+Usage: python tools/records_probe.py [n_bases] [k] [worlds, comma separated]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+sh = importlib.import_module(pkg.__name__ + ".shard_math")
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_000_000_000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+worlds = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+seed = 0xD2A0003
+rows = n - k + 1
+with pkg.Context(0) as ctx:
+    nb = ctx.sk_buckets(rows, k)
+    for W in worlds:
+        shards = sh.shard_ranges(n, k, W)
+        owners = sh.bucket_owner_ranges(nb, W)
+        recs, t_l0 = [], []
+        for first, cnt, lo, hi in shards:
+            d = ctx.synth(seed + lo // 32, hi - lo)
+            best = 1e9
+            r = None
+            for it in range(3):
+                if r is not None:
+                    r.free()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                r = ctx.sk_records(d, k, 0, cnt, rows)
+                ctx.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            t_l0.append(best)
+            recs.append(r)
+            d.free()
+        t_cnt, sent, recv, distinct = [], [], [], 0
+        for o, (lo_b, hi_b) in enumerate(owners):
+            pieces = [(r.device_ptr + 16 * int(r.offsets[b]), int(r.offsets[b + 1] - r.offsets[b]), b)
+                      for r in recs for b in range(lo_b, hi_b)]
+            recv.append(16 * sum(p[1] for p in pieces))
+            best = 1e9
+            for it in range(3 if o == 0 else 1):
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                h = ctx.count_records(pieces, k, rows)
+                ctx.synchronize()
+                best = min(best, time.perf_counter() - t0)
+                if it == 0:
+                    distinct += h.distinct
+                h.free()
+            t_cnt.append(best)
+        for ri, r in enumerate(recs):
+            lo_b, hi_b = owners[ri]
+            sent.append(16 * (r.n_records - int(r.offsets[hi_b] - r.offsets[lo_b])))
+            r.free()
+        print(json.dumps({"world": W, "n_bases": n, "k": k, "buckets": nb, "distinct": distinct,
+                          "level0_ms_max": round(max(t_l0) * 1e3, 3), "count_ms_rank0": round(t_cnt[0] * 1e3, 3),
+                          "count_ms_max": round(max(t_cnt) * 1e3, 3),
+                          "critical_path_ms": round((max(t_l0) + max(t_cnt)) * 1e3, 3),
+                          "sent_MB_max": round(max(sent) / 1e6, 1), "recv_MB_max": round(max(recv) / 1e6, 1)}), flush=True)
