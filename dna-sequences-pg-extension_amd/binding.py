@@ -142,6 +142,7 @@ def lib():
     L.dnagpu_multi_dna_free.argtypes = [vp, vp]
     L.dnagpu_multi_dna_free.restype = None
     L.dnagpu_count_multi.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_count_multi_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
     L.dnagpu_set_profiling.argtypes = [vp, C.c_int]
     L.dnagpu_set_debug.argtypes = [vp, C.c_uint]
@@ -581,6 +582,16 @@ class Multi:
             count = max(total - first, 0)
         hs = (C.c_void_p * self.n)()
         _chk(lib().dnagpu_count_multi(self.h, mdna, k, first, count, hs))
+        return [Hist(self.ranks[r], C.c_void_p(hs[r])) for r in range(self.n)]
+
+    def count_unordered(self, mdna, k, first=0, count=None):
+        """-> [Hist per rank]: the same groups, disjoint between ranks, in no key order (long k-mers: record exchange)"""
+        n_bases = int(lib().dnagpu_multi_dna_length(mdna))
+        total = kmer_count(n_bases, k)
+        if count is None:
+            count = max(total - first, 0)
+        hs = (C.c_void_p * self.n)()
+        _chk(lib().dnagpu_count_multi_unordered(self.h, mdna, k, first, count, hs))
         return [Hist(self.ranks[r], C.c_void_p(hs[r])) for r in range(self.n)]
 
     def close(self):

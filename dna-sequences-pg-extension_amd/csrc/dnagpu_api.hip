@@ -2651,3 +2651,103 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     return DNAGPU_OK;
     });
 }
+
+// The same count without any order promise, for long k-mers (k >= 23): the record exchange of sharded.py from one process.
+// Rank r cuts the records of the rows that start in its own chunk (one word of halo from its neighbour), every coarse
+// bucket's pieces are pulled by the bucket's owner (peer copies inside dnagpu_count_records: 16-byte records, 1.8 B per
+// k-mer at k = 31; nothing is gathered and no rank sweeps rows of another), and the owner counts them.
+// hists[r] = the groups of rank r's buckets: disjoint, in no key order.
+extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
+                                            dnagpu_hist **hists)
+{
+    return guarded([&]() -> int {
+    if (!m || !dna || !hists || (int)dna->view.size() != m->n)
+        return DNAGPU_ERR_BAD_ARG;
+    for (int r = 0; r < m->n; r++)
+        hists[r] = nullptr;
+    RC_TRY(check_range(dna->view[0], k, first, count));
+    if (k < sk_min_k() || count == 0)
+        return dnagpu_count_multi(m, dna, k, first, count, hists);         // (short k-mers: the ordered paths)
+    const int W = m->n;
+    std::vector<dnagpu_records *> recs((size_t)W, nullptr);
+    std::vector<int> rcs((size_t)W, DNAGPU_OK);
+    std::vector<std::string> errs((size_t)W);
+    auto run_all = [&](auto &&work) {
+        std::vector<std::thread> th;
+        for (int r = 1; r < W; r++)
+            th.emplace_back(work, r);
+        work(0);
+        for (std::thread &t : th)
+            t.join();
+    };
+    // ---- every rank: the records of its own rows
+    run_all([&](int r) {
+        dnagpu_ctx *c = m->ctx[(size_t)r];
+        const u64 w_lo = std::min((u64)r * dna->per, dna->n_words), w_hi = std::min((u64)(r + 1) * dna->per, dna->n_words);
+        const u64 row_lo = std::max<u64>(first, w_lo * 32), row_hi = std::min<u64>(first + count, w_hi * 32);
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess && r + 1 < W && w_hi < dna->n_words && row_hi > row_lo) {
+            const int src = r + 1;                 // the k-1 <= 31 bases a row reaches into the next chunk: one word
+            u64 *to = dna->full[(size_t)r] + w_hi;
+            const u64 *from = dna->full[(size_t)src] + w_hi;
+            e = m->dev[(size_t)src] == m->dev[(size_t)r] ? hipMemcpyAsync(to, from, 8, hipMemcpyDeviceToDevice, c->stream)
+                                                        : hipMemcpyPeerAsync(to, m->dev[(size_t)r], from, m->dev[(size_t)src], 8, c->stream);
+        }
+        if (e != hipSuccess) {
+            rcs[(size_t)r] = DNAGPU_ERR_HIP;
+            errs[(size_t)r] = hipGetErrorString(e);
+            return;
+        }
+        rcs[(size_t)r] = dnagpu_sk_records(c, dna->view[(size_t)r], k, row_hi > row_lo ? row_lo : 0, row_hi > row_lo ? row_hi - row_lo : 0,
+                                           count, &recs[(size_t)r]);
+        if (rcs[(size_t)r] != DNAGPU_OK)
+            errs[(size_t)r] = dnagpu_last_error();
+    });
+    int rc = DNAGPU_OK;
+    for (int r = 0; r < W && rc == DNAGPU_OK; r++)
+        if (rcs[(size_t)r] != DNAGPU_OK) {
+            set_err("rank %d (records): %s", r, errs[(size_t)r].c_str());
+            rc = rcs[(size_t)r];
+        }
+    // ---- every owner: its buckets' pieces from all ranks
+    if (rc == DNAGPU_OK) {
+        const u32 nb = dnagpu_records_buckets(recs[0]);
+        run_all([&](int o) {
+            const u32 b_lo = (u32)(((u64)o * nb + (u64)W - 1) / (u64)W), b_hi = (u32)(((u64)(o + 1) * nb + (u64)W - 1) / (u64)W);
+            std::vector<const void *> ptr;
+            std::vector<u64> len;
+            std::vector<u32> bk;
+            for (int src = 0; src < W; src++)
+                for (u32 b = b_lo; b < b_hi; b++) {
+                    const dnagpu_records *rr = recs[(size_t)src];
+                    const u64 n_b = rr->off[b + 1] - rr->off[b];
+                    if (n_b) {
+                        ptr.push_back(static_cast<const char *>(rr->recs) + rr->off[b] * 16);
+                        len.push_back(n_b);
+                        bk.push_back(b);
+                    }
+                }
+            rcs[(size_t)o] = dnagpu_count_records(m->ctx[(size_t)o], ptr.data(), len.data(), bk.data(), (u32)ptr.size(), k, count,
+                                                  &hists[o]);
+            if (rcs[(size_t)o] != DNAGPU_OK)
+                errs[(size_t)o] = dnagpu_last_error();
+        });
+        for (int r = 0; r < W && rc == DNAGPU_OK; r++)
+            if (rcs[(size_t)r] != DNAGPU_OK) {
+                set_err("rank %d (count): %s", r, errs[(size_t)r].c_str());
+                rc = rcs[(size_t)r];
+            }
+    }
+    for (int r = 0; r < W; r++) {
+        (void)hipSetDevice(m->ctx[(size_t)r]->device);
+        dnagpu_records_free(m->ctx[(size_t)r], recs[(size_t)r]);
+        if (rc != DNAGPU_OK) {
+            dnagpu_hist_free(m->ctx[(size_t)r], hists[r]);
+            hists[r] = nullptr;
+        }
+    }
+    (void)hipSetDevice(m->ctx[0]->device);
+    return rc;
+    });
+}
+

@@ -560,7 +560,7 @@ CountKmers *count_kmers_begin(Dna *dna, int k)
             c->n_ranks = g_n_gpus;
             for (int r = 0; r < c->n_ranks; r++)
                 c->hctx[r] = dnagpu_multi_ctx(m, r);
-            ok = gpu_ok(dnagpu_count_multi(m, md, k, 0, n_rows, c->hist));
+            ok = gpu_ok(dnagpu_count_multi_unordered(m, md, k, 0, n_rows, c->hist));   /* GROUP BY promises no order */
             dnagpu_multi_dna_free(m, md);
         }
     } else {

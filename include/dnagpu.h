@@ -305,6 +305,14 @@ void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d);
  * result, the other ranks' histograms are empty -- the same concatenation property. */
 int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                        dnagpu_hist **hists);
+/* The same groups with no order promise (PostgreSQL's GROUP BY makes none, test.sql:95-104), for long k-mers (k >= 23;
+ * shorter ones go through dnagpu_count_multi): the record exchange above from one process.  Nothing is gathered:
+ * rank r cuts the super-k-mer records of the rows that start in its own chunk, the owner of a coarse bucket pulls the
+ * bucket's pieces from every rank (peer copies of 16-byte records, 1.8 B per k-mer at k = 31) and counts them.
+ * hists[r] = the groups of rank r's buckets: disjoint between ranks, dnagpu_hist_is_sorted == 0, sum of
+ * dnagpu_hist_total = count. */
+int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
+                                 dnagpu_hist **hists);
 
 /* ---- batched operators over arrays of keys (bulk scans of stored kmer columns) -------------- */
 

@@ -877,6 +877,30 @@ def test_count_multi_one_process(pkg, n_ranks):
             m.dna_free(d)
 
 
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+def test_count_multi_unordered_one_process(pkg, n_ranks):
+    """dnagpu_count_multi_unordered: the record exchange from one process (every rank on device 0: chunk residency, the
+    halo word, per-rank records, the owners' pulls of their buckets' pieces are the product code).  The ranks' groups are
+    disjoint and together the oracle's histogram; short k-mers take the ordered paths."""
+    n, seed = 3_000_017, 0xD2A0003
+    words = orc.synth_words(seed, n)
+    with pkg.Multi([0] * n_ranks, pkg.MULTI_COPY) as m:
+        for make in ("synth", "upload"):
+            d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
+            for k, first, count in ((31, 0, None), (27, 1000, 2_000_000), (23, 31, None), (32, 0, 1_234_567), (8, 0, None)):
+                ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False)[first:None if count is None else first + count])
+                hs = m.count_unordered(d, k, first, count)
+                gk = np.concatenate([h.download()[0] for h in hs])
+                gc = np.concatenate([h.download()[1] for h in hs])
+                assert sum(h.total for h in hs) == int(oc.sum())
+                order = np.argsort(gk, kind="stable")
+                assert_same(gk[order], ok, f"multi unordered {n_ranks} ranks ({make}) k={k} keys")
+                assert_same(gc[order], oc, f"multi unordered {n_ranks} ranks ({make}) k={k} counts")
+                for h in hs:
+                    h.free()
+            m.dna_free(d)
+
+
 def test_count_multi_rccl_one_rank(pkg, ctx):
     """the RCCL transport (librccl.so loaded on demand, ncclCommInitAll) with the one device a test box has"""
     ctx.trim()          # the module's context has pooled the full-size configs' work buffers: RCCL allocates on its own
