@@ -323,8 +323,6 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             }
             if ((tid & 63) == 0)
                 wtot[tid >> 6] = wrun;
-            for (u32 d = tid; d < 2u * SK_MAX_C0; d += SK_NT)
-                hx[d] = 0;                         // (digit counters and their offsets, below: the front end is done with hx)
             __syncthreads();
             u32 tile_recs = 0, wmax = 0;
             u32 wbase[SK_NT / 64 + 1];
@@ -341,19 +339,8 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                 __syncthreads();
                 continue;
             }
-            // The tile's records leave in DIGIT order: ranked by coarse digit (one returning LDS add each), an index list
-            // of the ranked order (in hs, which the front end is done with), then lane s builds and stores the s-th record
-            // of that order -- a digit's ~14 records of the tile are one contiguous ~224-byte piece from adjacent lanes
-            // instead of 16-byte stores all over the wave (measured with the stores alone: 2.6 of the kernel's 5.1 ms).
-            unsigned short *idx = reinterpret_cast<unsigned short *>(hs);   // [SK_LIST]
-            u32 *cnt = hx, *cbase = hx + SK_MAX_C0;                         // (hx holds 2 * SK_NT + 8 words)
-            constexpr int EPT = SK_LIST / SK_NT;                            // list entries per thread
-            u32 pk[EPT];                                                    // list slot << 20 | rank << 8 | digit
-#pragma unroll
-            for (int i = 0; i < EPT; i++) {
-                const u32 e = (u32)tid + (u32)i * SK_NT;
-                pk[i] = 0;
-                if (e < tile_recs) {
+            if (!SK_DBG(2))
+                for (u32 e = tid; e < tile_recs; e += SK_NT) {
                     u32 wq = 0;
 #pragma unroll
                     for (int q = 1; q < SK_NT / 64; q++)
@@ -362,30 +349,9 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
 #pragma unroll
                     for (int q = 1; q < SK_NT / 64; q++)
                         eb = wq == (u32)q ? wbase[q] : eb;
-                    const u32 slot = wq * WCAP + (e - eb);
-                    const u32 d0 = sk_digits((u32)(list[slot] >> 32), c0n, b1mask).d0;
-                    const u32 rank = atomicAdd(&cnt[d0], 1u);
-                    pk[i] = (slot << 20) | (rank << 8) | d0;
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {                        // exclusive scan of the <= 128 digit counts: two per lane
-                const u32 v0 = 2 * tid < (int)r0n ? cnt[2 * tid] : 0u, v1 = 2 * tid + 1 < (int)r0n ? cnt[2 * tid + 1] : 0u;
-                const u32 inc = wave_incl_scan(v0 + v1);
-                cbase[2 * tid] = inc - v0 - v1;
-                cbase[2 * tid + 1] = inc - v1;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < EPT; i++)
-                if ((u32)tid + (u32)i * SK_NT < tile_recs)
-                    idx[cbase[pk[i] & 255u] + ((pk[i] >> 8) & 0xFFFu)] = (unsigned short)(pk[i] >> 20);
-            __syncthreads();
-            if (!SK_DBG(2))
-                for (u32 s = tid; s < tile_recs; s += SK_NT) {
-                    const u64 en = list[idx[s]];
+                    const u64 en = list[wq * WCAP + (e - eb)];
                     const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
-                    const u32 gslot = gpos[dg.d0] + (s - cbase[dg.d0]);
+                    const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
                     const u32 len = ((u32)en & 31u) + 1u;
                     const u32 q = ((u32)(en >> 5) & 0x1FFFu) + fo; // first base of the run, relative to the tile's first word
                     const u32 wi = q >> 5, sh = (q & 31u) * 2u;
@@ -407,9 +373,6 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     else if (r.x == 0x1234567 && r.y == 0x89)
                         recs[0] = r;
                 }
-            __syncthreads();                       // (every reader of gpos / cnt / cbase is done)
-            for (u32 d = tid; d < r0n; d += SK_NT)
-                gpos[d] += cnt[d];
             __syncthreads();                       // wsh / list are rewritten by the next pass / tile
         }
     }
