@@ -983,7 +983,7 @@ def test_config3_k31_chr1_scale_properties(ctx):
     d.free()
 
 
-def test_config4_k31_3G_properties(ctx):
+def test_config4_k31_3G_properties(ctx, pkg):
     """configs[3] at its full size on one GPU: k=31 over 3 Gbase, seed 0xD2A0003 (the bench workload).
     Size-independent properties: sum(count) = number of rows; groups strictly ascending inside and
     across download windows; the eight owners' histograms (the sharded path) are disjoint and their
@@ -1017,5 +1017,33 @@ def test_config4_k31_3G_properties(ctx):
         t_sum, d_sum, u_sum, c_sum = t_sum + t, d_sum + dd, u_sum + u, (c_sum + c) & M
         ho.free()
     assert (t_sum, d_sum, u_sum, c_sum) == (total, distinct, unique, checksum)
+    # the unordered entry point (super-k-mer engine: the bench's default workload): the same groups, i.e. the same digest
+    hu = ctx.count_kmers_unordered(d, k)
+    assert not hu.is_sorted, "3 Gbase k=31 is expected to go through the super-k-mer engine"
+    assert hu.summary() == (total, distinct, unique, checksum)
+    hu.free()
     d.free()
+    ctx.trim()
+    # the record exchange at full size, eight "ranks" in this process: every rank's records from its own shard (+ halo),
+    # every owner's count over its buckets' pieces; the owners' digests add up to the single-GPU digest
+    import importlib
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
+    rows = n - k + 1
+    nb = ctx.sk_buckets(rows, k)
+    recs = []
+    for first, cnt, lo, hi in sh.shard_ranges(n, k, 8):
+        ds = ctx.synth(seed + lo // 32, hi - lo)
+        recs.append(ctx.sk_records(ds, k, 0, cnt, rows))
+        ds.free()
+    t_sum = d_sum = u_sum = c_sum = 0
+    for lo_b, hi_b in sh.bucket_owner_ranges(nb, 8):
+        pieces = [(r.device_ptr + 16 * int(r.offsets[b]), int(r.offsets[b + 1] - r.offsets[b]), b) for r in recs for b in range(lo_b, hi_b)]
+        ho = ctx.count_records(pieces, k, rows)
+        t, dd, u, c = ho.summary()
+        assert ho.total == t
+        t_sum, d_sum, u_sum, c_sum = t_sum + t, d_sum + dd, u_sum + u, (c_sum + c) & M
+        ho.free()
+    for r in recs:
+        r.free()
+    assert (t_sum, d_sum, u_sum, c_sum) == (total, distinct, unique, checksum)
     ctx.trim()
