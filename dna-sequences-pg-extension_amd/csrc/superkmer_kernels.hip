@@ -847,11 +847,17 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   the waves); a binary search over the prefix instead of the owner table (19.6 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
-constexpr int SKC_SLOTS = 106 * 64;              // 6784 slots (load 0.49 at 3300 keys): with the tables below 79.9 KiB, two workgroups per CU
+constexpr int SKC_SLOTS = 212 * 64;              // 13568 four-byte slots (load 0.24 at 3300 keys): with the tables below 79.2 KiB, two workgroups per CU
 constexpr int SKC_MAXREC = 512;                  // records of a bucket (a bucket of 3300 k-mers of random sequence has ~370)
 constexpr int SKC_KPT = 4;                       // k-mers per quad
 constexpr int SKC_MAXQ = SKC_NT;                 // quads of a bucket: one per thread (the selection sends buckets with more elsewhere)
-constexpr u64 SKC_EMPTY = ~(u64)0;
+constexpr u32 SKC_FREE = ~0u;                    // an empty slot
+
+// k-mer j of a record
+__device__ __forceinline__ u64 sk_record_kmer(const ull2_t rec, u32 j, u64 kmask)
+{
+    return funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j) & kmask;
+}
 
 __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
                                                              u32 n_list, const ull2_t *__restrict__ recs, int k,
@@ -861,26 +867,30 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
 {
     constexpr int WAVES = SKC_NT / 64;
     constexpr int RWAVES = SKC_MAXREC / 64;        // waves that hold records
-    __shared__ __attribute__((aligned(16))) u64 tab[SKC_SLOTS];
-    __shared__ __attribute__((aligned(16))) u32 cnt2[SKC_SLOTS / 2];
-    unsigned short *cnt16 = reinterpret_cast<unsigned short *>(cnt2);
+    // A slot holds 20 bits of fingerprint and the 12-bit id of the k-mer that claimed it (thread << 2 | position in its
+    // quad) -- four bytes instead of the key's eight, so the same LDS gives twice the slots and probe chains half as
+    // long (the kernel is bound by LDS instructions per bucket, and a probe chain is as long as its slowest lane's).
+    // An insert that meets its own fingerprint re-derives the claimant's key from the staged records (owner table ->
+    // record -> shift) and compares in full: equal = a copy, counted at the claimant's id; different = a fingerprint
+    // collision (one comparison in 2^20), which just probes on.  No key value is reserved.
+    __shared__ __attribute__((aligned(16))) u32 tab[SKC_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 cop2[SKC_NT * SKC_KPT / 2];    // copies per claimant id, 16-bit halves
+    unsigned short *cop16 = reinterpret_cast<unsigned short *>(cop2);
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
     __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
     __shared__ u64 sh_obase[2];
-    __shared__ u32 ones_cnt[2], copy_seen[2];
+    __shared__ u32 copy_seen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 lq = blockIdx.x;
     if (lq >= n_list)
         return;
     for (int q = tid; q < SKC_SLOTS; q += SKC_NT)
-        tab[q] = SKC_EMPTY;
-    for (int q = tid; q < SKC_SLOTS / 2; q += SKC_NT)
-        cnt2[q] = 0;
-    if (tid < 2) {
-        ones_cnt[tid] = 0;
+        tab[q] = SKC_FREE;
+    for (int q = tid; q < SKC_NT * SKC_KPT / 2; q += SKC_NT)
+        cop2[q] = 0;
+    if (tid < 2)
         copy_seen[tid] = 0;
-    }
     const u64 kmask = kmer_mask(k);
     const u64 below = ((u64)1 << lane) - 1;
     u32 li = list[lq];
@@ -895,7 +905,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     constexpr int KEEP = SKC_KPT;
     u64 pk[KEEP];
     u32 pc[KEEP];
-    u32 p_mask = 0, p_before = 0, p_groups = 0, p_ones = 0, p_li = 0;
+    u32 p_mask = 0, p_before = 0, p_groups = 0, p_li = 0;
     u64 ob_pending = 0;
     bool have_prev = false;
     int par = 0;
@@ -915,10 +925,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                 out_counts[o] = pc[q];
             }
             run += (u32)__popcll(b);
-        }
-        if (p_ones && tid == 0) {
-            out_keys[obase + p_groups - 1] = SKC_EMPTY;
-            out_counts[obase + p_groups - 1] = p_ones;
         }
         if (tid == 0) {
             seg_off[p_li] = obase;
@@ -984,23 +990,30 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                     if (SK_DBG(32)) {
                         c_mask |= (kv & 1) ? 1u << q : 0u;
                         ck[q] = kv;
-                    } else if (kv == SKC_EMPTY) {
-                        atomicAdd(&ones_cnt[par], 1u);
                     } else {
-                        u32 slot = (((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 16) * (u32)SKC_SLOTS) >> 16;
+                        const u32 x = ((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u;
+                        u32 slot = ((x >> 16) * (u32)SKC_SLOTS) >> 16;
+                        u32 fp = (x ^ (u32)(kv >> 39)) & 0xFFFFFu;
+                        fp = fp == 0xFFFFFu ? 0u : fp;                       // (fp = all ones with id 4095 would read as a free slot)
+                        const u32 word = (fp << 12) | ((u32)tid << 2) | (u32)q;
                         for (;;) {
-                            const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
-                                                      (unsigned long long)SKC_EMPTY, (unsigned long long)kv);
-                            if (old == SKC_EMPTY) {
+                            const u32 old = atomicCAS(&tab[slot], SKC_FREE, word);
+                            if (old == SKC_FREE) {
                                 c_mask |= 1u << q;
                                 ck[q] = kv;
                                 cslot[q] = slot;
                                 break;
                             }
-                            if (old == kv) {       // a copy of a key already in the table: only copies are counted beside it
-                                atomicAdd(&cnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
-                                copy_seen[par] = 1u;
-                                break;
+                            if ((old >> 12) == fp) {
+                                // the claimant's key, from the staged records (its owner entry and record do not change before B)
+                                const u32 oid = old & 0xFFFu;
+                                const u32 oe = ownq[oid >> 2];
+                                const u64 okey = sk_record_kmer(lrec[oe & 511u], (oe >> 9) * SKC_KPT + (oid & 3u), kmask);
+                                if (okey == kv) {  // a copy: counted at the claimant's id
+                                    atomicAdd(&cop2[oid >> 1], 1u << ((oid & 1u) * 16u));
+                                    copy_seen[par] = 1u;
+                                    break;
+                                }
                             }
                             slot = slot + 1 == (u32)SKC_SLOTS ? 0u : slot + 1;
                         }
@@ -1019,31 +1032,29 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
         u32 before = 0, D = 0;
         sk_wave_prefix16(wclaim[par], WAVES, wave, lane, before, D);
-        const bool any_copy = copy_seen[par] != 0; // (random sequence: no bucket has one, and the count table is not read)
+        const bool any_copy = copy_seen[par] != 0; // (random sequence: no bucket has one, and the copy counters are not read)
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
             pk[q] = ck[q];
             pc[q] = 0;
             if ((c_mask >> q) & 1u) {
                 pc[q] = 1u;
-                tab[cslot[q]] = SKC_EMPTY;
+                tab[cslot[q]] = SKC_FREE;
                 if (any_copy) {
-                    const u32 copies = cnt16[cslot[q]];
+                    const u32 copies = cop16[(u32)tid * SKC_KPT + (u32)q];
                     pc[q] = 1u + copies;
                     if (copies)
-                        cnt16[cslot[q]] = 0;
+                        cop16[(u32)tid * SKC_KPT + (u32)q] = 0;
                 }
             }
         }
         p_mask = c_mask;
         p_before = before;
-        p_ones = ones_cnt[par];
-        p_groups = D + (p_ones ? 1u : 0u);
+        p_groups = D;
         p_li = li;
         if (tid == 0) {
             ob_pending = atomicAdd(cursor, (unsigned long long)p_groups);
-            ones_cnt[par ^ 1] = 0;                 // (the other parity's counters: its bucket has been emitted)
-            copy_seen[par ^ 1] = 0;
+            copy_seen[par ^ 1] = 0;                // (the other parity's flag: its bucket has been emitted)
         }
         have_prev = true;
         par ^= 1;
