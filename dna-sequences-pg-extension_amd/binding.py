@@ -110,6 +110,8 @@ def lib():
     L.dnagpu_hist_distinct.restype = C.c_uint64
     L.dnagpu_hist_total.argtypes = [vp]
     L.dnagpu_hist_total.restype = C.c_uint64
+    L.dnagpu_hist_extent.argtypes = [vp]
+    L.dnagpu_hist_extent.restype = C.c_uint64
     L.dnagpu_hist_device_keys.argtypes = [vp]
     L.dnagpu_hist_device_keys.restype = vp
     L.dnagpu_hist_device_counts.argtypes = [vp]
@@ -252,6 +254,11 @@ class Hist:
     @property
     def total(self):
         return int(lib().dnagpu_hist_total(self.h))
+
+    @property
+    def extent(self):
+        """slots of device_keys / device_counts in use (an unordered histogram may hold count-0 padding slots)"""
+        return int(lib().dnagpu_hist_extent(self.h))
 
     @property
     def device_keys(self):

@@ -1779,20 +1779,20 @@ __global__ __launch_bounds__(256) void class_list_kernel(const Node *__restrict_
 
 __global__ __launch_bounds__(256) void emit_singles_kernel(const Node *__restrict__ leaves, u32 n_leaves,
                                                            const u32 *__restrict__ pre, const u32 *__restrict__ total,
-                                                           unsigned long long *__restrict__ cursor,
+                                                           unsigned long long *__restrict__ cursor, u64 out_base,
                                                            u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
                                                            u64 *__restrict__ out_keys, u32 *__restrict__ out_counts)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0)
-        *cursor = *total;                          // the sorting leaves allocate behind the singles
+        *cursor = out_base + *total;               // the sorting leaves allocate behind the singles
     if (i >= n_leaves)
         return;
     const Node nd = leaves[i];
     const bool sorts = nd.len > 0 && (nd.meta & 0xff) != 0 && !(nd.meta & NODE_TERMINAL);
     if (sorts)
         return;
-    const u32 o = pre[i];
+    const u64 o = out_base + pre[i];
     seg_off[i] = o;
     seg_cnt[i] = nd.len > 0 ? 1u : 0u;
     if (nd.len > 0) {
@@ -1941,7 +1941,7 @@ __global__ __launch_bounds__(HL_NT, 4) void hash_leaves_kernel(const Node *__res
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0,
                          const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed)
+                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed, u64 out_base)
 {
     if (n_leaves == 0)
         return hipSuccess;
@@ -1964,7 +1964,7 @@ hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_sma
         if (e != hipSuccess)
             return e;
         hipLaunchKernelGGL(emit_singles_kernel, dim3(g), dim3(256), 0, s, leaves, n_leaves, flags, flags + n_leaves, cur,
-                           seg_off, seg_cnt, out_keys, out_counts);
+                           out_base, seg_off, seg_cnt, out_keys, out_counts);
     }
 #ifdef DNAGPU_STAMPS
 #define LEAVES_STAMPS(name) stamps_report("leaves " name, 0, s)

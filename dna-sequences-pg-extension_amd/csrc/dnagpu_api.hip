@@ -134,6 +134,8 @@ struct dnagpu_hist {
     u32 *seg_pre;     // exclusive scan of seg_cnt, built on first ordered download
     u32 n_segs;
     bool sorted;      // the segments are consecutive key ranges (true unless the super-k-mer engine made them)
+    u64 extent;       // slots of keys / counts in use: n_distinct, or more when an unordered histogram holds count-0 padding
+                      // between segments (0 = n_distinct)
 };
 
 // DNAGPU_DEBUG_POISON_POOL: no work buffer starts out zeroed (fresh hipMalloc memory) or holding a
@@ -1543,35 +1545,46 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     const u32 n_heavy = heavy.n;
     prof_mark(ctx, "sk_select");
     const u32 cap = (u32)sk_count_cap();
-    u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *scan_tmp = nullptr, *totals = nullptr, *list_small = nullptr;
+    u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *k_small = nullptr, *scan_tmp = nullptr, *totals = nullptr,
+        *list_small = nullptr, *off_small = nullptr;
     RC_TRY(ps.alloc((size_t)n_fin, &f_small));
     RC_TRY(ps.alloc((size_t)n_fin, &f_over));
     RC_TRY(ps.alloc((size_t)n_fin, &k_over));
+    RC_TRY(ps.alloc((size_t)n_fin, &k_small));
     RC_TRY(ps.alloc((size_t)scan_tmp_words(n_fin), &scan_tmp));
     RC_TRY(ps.alloc(4, &totals));
     RC_TRY(ps.alloc((size_t)n_fin, &list_small));
-    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, f_small, f_over, k_over, st));
+    RC_TRY(ps.alloc((size_t)n_fin, &off_small));
+    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, f_small, f_over, k_over, k_small, st));
     HIP_TRY(launch_scan_u32(f_small, f_small, n_fin, scan_tmp, totals + 0, st));
     HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 1, st));
     HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 2, st));
-    u32 ht[3] = {0, 0, 0};
+    HIP_TRY(launch_scan_u32(k_small, k_small, n_fin, scan_tmp, totals + 3, st));
+    u32 ht[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ht, totals, sizeof ht, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const u32 n_small = ht[0], n_over = ht[1];
     const u64 over_keys = ht[2];
+    const u64 small_keys = ht[3];                // the output slots sk_count's buckets take: one per k-mer, in list order
     Node *over_nodes = nullptr;
     u32 *over_kbase = nullptr;
     RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_nodes));
     RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_kbase));
-    HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, f_small, f_over, k_over, list_small, over_nodes, over_kbase, st));
+    HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, f_small, f_over, k_over, k_small, list_small, off_small, over_nodes, over_kbase, st));
 
     // output arrays and the segment directory: final buckets first, the nodes of the oversize buckets' tree behind them
     u64 *cursor = nullptr, *ok = nullptr;
     u32 *oc = nullptr;
-    RC_TRY(ps.alloc(2, &cursor));                // [0] groups written so far; [1] buckets whose expansion disagrees with the partition's count
+    // [0] next free output slot of the leaves behind sk_count's ranges; [1] buckets whose expansion disagrees with the
+    // partition's count; [2] groups sk_count wrote
+    RC_TRY(ps.alloc(3, &cursor));
     RC_TRY(ps.alloc((size_t)n, &ok));
     RC_TRY(ps.alloc((size_t)n, &oc));
-    HIP_TRY(hipMemsetAsync(cursor, 0, 16, st));
+    {
+        const u64 init[3] = {small_keys, 0, 0};
+        HIP_TRY(hipMemcpyAsync(cursor, init, sizeof init, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));       // (init is a stack variable)
+    }
     TreeResult tr;
     memset(&tr, 0, sizeof tr);
     u64 *seg_off = nullptr;
@@ -1633,15 +1646,16 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
         RC_TRY(ps.alloc((size_t)tr.n_nodes, &cls_list));
         prof_mark(ctx, "leaves");
         HIP_TRY(launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off + n_fin,
-                              seg_cnt + n_fin, ok, oc, flags, ltmp, cls_list, st, true));
+                              seg_cnt + n_fin, ok, oc, flags, ltmp, cls_list, st, true, small_keys));
     }
     prof_mark(ctx, "sk_count");
-    HIP_TRY(launch_sk_count(fin, list_small, n_small, recs, k, cursor, seg_off, seg_cnt, ok, oc, st));
+    HIP_TRY(launch_sk_count(fin, list_small, off_small, n_small, recs, k, cursor + 2, seg_off, seg_cnt, ok, oc, st));
     prof_mark(ctx, "end");
-    u64 fin_ctr[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(fin_ctr, cursor, 16, hipMemcpyDeviceToHost, st));
+    u64 fin_ctr[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(fin_ctr, cursor, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const u64 total_groups = fin_ctr[0];
+    const u64 extent = fin_ctr[0];
+    const u64 total_groups = fin_ctr[2] + (extent - small_keys);
     if (fin_ctr[1] != 0) {
         set_err("super-k-mer count: %llu buckets whose records expand to a different number of k-mers than the partition counted",
                 (unsigned long long)fin_ctr[1]);
@@ -1653,6 +1667,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     }
     h->total = n;
     h->n_distinct = total_groups;
+    h->extent = extent;
     h->keys = ok;
     h->counts = oc;
     h->seg_off = seg_off;
@@ -2023,6 +2038,7 @@ extern "C" int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, u
 extern "C" uint64_t dnagpu_hist_distinct(const dnagpu_hist *h) { return h ? h->n_distinct : 0; }
 extern "C" uint64_t dnagpu_hist_total(const dnagpu_hist *h) { return h ? h->total : 0; }
 extern "C" const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h) { return h ? h->keys : nullptr; }
+extern "C" uint64_t dnagpu_hist_extent(const dnagpu_hist *h) { return !h ? 0 : (h->extent ? h->extent : h->n_distinct); }
 extern "C" const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
 
 // Ascending-key order through the segment directory: groups are gathered on the device into a
@@ -2115,7 +2131,7 @@ extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64
     u64 *res = nullptr;
     RC_TRY(ps.alloc(4, &res));
     HIP_TRY(hipMemsetAsync(res, 0, 32, ctx->stream));
-    HIP_TRY(launch_hist_summary(h->keys, h->counts, h->n_distinct, res, ctx->stream));
+    HIP_TRY(launch_hist_summary(h->keys, h->counts, h->extent ? h->extent : h->n_distinct, res, ctx->stream));
     u64 r[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(r, res, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void hist_summary_kernel(const u64 *__restrict
     u64 stride = (u64)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         u64 cnt = counts[i];
+        if (cnt == 0)                            // padding of an unordered histogram (a bucket that held copies)
+            continue;
         t += cnt;
         u += cnt == 1;
         c += pair_mix(keys[i], cnt);

@@ -130,7 +130,8 @@ hipError_t launch_level_scatter(const Node *nodes, const Chunk *chunks, u32 n_ch
 // nodes are sorting leaves of one class
 hipError_t launch_leaves(const Node *leaves, u32 n_leaves, u32 n_tiny, u32 n_small, u32 n_big, const u64 *buf0, const u64 *buf1,
                          u64 *cursor, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *flags,
-                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed = false);
+                         u32 *scan_tmp, u32 *list, hipStream_t s, bool hashed = false, u64 out_base = 0);
+// (out_base: the value *cursor holds at the call -- the first output slot these leaves may use)
 // dense count of short k-mers straight from the packed sequence (2k = bits <= dense_max_bits()): table must hold
 // 2^bits u32 counters, out_keys/out_counts 2^bits entries; *n_out = distinct keys; results ascending
 int dense_max_bits();
@@ -178,13 +179,17 @@ hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const 
 hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s);
 // final buckets list[0..n_list) (indices into fin) counted from their records in an LDS hash table; groups appended
 // at *cursor, seg_off / seg_cnt[bucket] = where they went
-hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const void *recs, int k, u64 *cursor, u64 *seg_off,
-                           u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
+// list_off[i] = first output slot of bucket list[i] (its range is as long as its k-mers; slots past its distinct keys are
+// count-0 padding); *n_groups += the groups written
+hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
+                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
 
 int sk_count_cap();       // most k-mers a final bucket may hold to be counted from its records
-hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, hipStream_t s);
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, u32 *k_small,
+                                  hipStream_t s);
 hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
-                                  u32 *list_small, Node *over_nodes, u32 *over_kbase, hipStream_t s);
+                                  const u32 *kb_small, u32 *list_small, u32 *off_small, Node *over_nodes, u32 *over_kbase,
+                                  hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();

@@ -860,8 +860,9 @@ __device__ __forceinline__ u64 sk_record_kmer(const ull2_t rec, u32 j, u64 kmask
 }
 
 __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
-                                                             u32 n_list, const ull2_t *__restrict__ recs, int k,
-                                                             unsigned long long *__restrict__ cursor,
+                                                             const u32 *__restrict__ list_off, u32 n_list,
+                                                             const ull2_t *__restrict__ recs, int k,
+                                                             unsigned long long *__restrict__ n_groups,
                                                              u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
                                                              u64 *__restrict__ out_keys, u32 *__restrict__ out_counts, int dbg)
 {
@@ -879,7 +880,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
     __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
-    __shared__ u64 sh_obase[2];
     __shared__ u32 copy_seen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 lq = blockIdx.x;
@@ -894,7 +894,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     const u64 kmask = kmer_mask(k);
     const u64 below = ((u64)1 << lane) - 1;
     u32 li = list[lq];
-    Node nd = fin[li];
+    u32 off = list_off[lq];                        // the bucket's output range is [off, off + its k-mers): the exclusive scan of
+    Node nd = fin[li];                             // the buckets' k-mer counts, so no cursor is involved
     ull2_t myrec;                                  // record tid of the bucket (threads 0 .. SKC_MAXREC-1)
     myrec.x = myrec.y = 0;
     if ((u32)tid < nd.len)
@@ -905,15 +906,15 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     constexpr int KEEP = SKC_KPT;
     u64 pk[KEEP];
     u32 pc[KEEP];
-    u32 p_mask = 0, p_before = 0, p_groups = 0, p_li = 0;
-    u64 ob_pending = 0;
-    bool have_prev = false;
+    u32 p_mask = 0, p_before = 0, p_groups = 0, p_li = 0, p_off = 0, p_kmers = 0;
+    bool have_prev = false, p_copy = false;
+    u64 my_groups = 0;                             // (thread 0: groups of all this workgroup's buckets)
     int par = 0;
 
-    auto emit_prev = [&](int pp) {
+    auto emit_prev = [&]() {
         // every wave's claimed keys go out position by position: lanes that claimed their q-th key write one
         // contiguous run per store instruction
-        const u64 obase = sh_obase[pp];
+        const u64 obase = p_off;
         u32 run = p_before;
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
@@ -926,6 +927,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             }
             run += (u32)__popcll(b);
         }
+        if (p_copy)                                // a bucket that held copies: the rest of its range is count-0 padding
+            for (u32 i = p_groups + (u32)tid; i < p_kmers; i += SKC_NT)
+                out_counts[obase + i] = 0;
         if (tid == 0) {
             seg_off[p_li] = obase;
             seg_cnt[p_li] = p_groups;
@@ -936,6 +940,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u32 lq_next = lq + gridDim.x;
         const bool has_next = lq_next < n_list;
         const u32 ln = has_next ? list[lq_next] : li;
+        const u32 off_next = has_next ? list_off[lq_next] : off;
         const Node nn = fin[ln];
         // ---- records into LDS; prefix over their quad counts (record threads only)
         const u32 len = (u32)tid < nd.len ? (u32)((myrec.y >> 44) & 31) + 1u : 0u;
@@ -1024,11 +1029,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u32 wc = wave_sum((u32)__popc(c_mask));
         if (lane == 0)
             wclaim[par][wave] = wc;
-        if (tid == 0 && have_prev)
-            sh_obase[par ^ 1] = ob_pending;        // (requested one bucket ago: the wait for it ends here at the latest)
-        __syncthreads();                           // B: all inserts done; the previous bucket's range is known
+        __syncthreads();                           // B: all inserts done
         if (have_prev)
-            emit_prev(par ^ 1);
+            emit_prev();                           // (a bucket behind: its stores overlap this bucket's tail and the next one's head)
         // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
         u32 before = 0, D = 0;
         sk_wave_prefix16(wclaim[par], WAVES, wave, lane, before, D);
@@ -1052,9 +1055,12 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         p_before = before;
         p_groups = D;
         p_li = li;
+        p_off = off;
+        p_kmers = nd.child_base;
+        p_copy = any_copy;
         if (tid == 0) {
-            ob_pending = atomicAdd(cursor, (unsigned long long)p_groups);
-            copy_seen[par ^ 1] = 0;                // (the other parity's flag: its bucket has been emitted)
+            my_groups += D;
+            copy_seen[par ^ 1] = 0;                // (the other parity's flag: its bucket is done with it)
         }
         have_prev = true;
         par ^= 1;
@@ -1062,19 +1068,18 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             break;
         lq = lq_next;
         li = ln;
+        off = off_next;
         nd = nn;
     }
-    // the last bucket's output
+    emit_prev();                                   // the last bucket's output
     if (tid == 0)
-        sh_obase[par ^ 1] = ob_pending;
-    __syncthreads();
-    emit_prev(par ^ 1);
+        atomicAdd(n_groups, (unsigned long long)my_groups);
 }
 
 static int sk_dbg();
 
-hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const void *recs, int k, u64 *cursor, u64 *seg_off,
-                           u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
+hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
+                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
 {
     if (n_list == 0)
         return hipSuccess;
@@ -1082,8 +1087,9 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const v
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
         n_cu = v;
     const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
-    hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, n_list, reinterpret_cast<const ull2_t *>(recs),
-                       k, reinterpret_cast<unsigned long long *>(cursor), seg_off, seg_cnt, out_keys, out_counts, sk_dbg());
+    hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, list_off, n_list,
+                       reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
+                       out_keys, out_counts, sk_dbg());
     return hipGetLastError();
 }
 
@@ -1092,7 +1098,7 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, u32 n_list, const v
 // others are expanded to keys for the ordinary levels (compact copies in over_nodes, their key ranges in over_kbase)
 __global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
                                                               u32 *__restrict__ f_small, u32 *__restrict__ f_over,
-                                                              u32 *__restrict__ k_over)
+                                                              u32 *__restrict__ k_over, u32 *__restrict__ k_small)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fin)
@@ -1102,11 +1108,13 @@ __global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__rest
     f_small[i] = km > 0 && small ? 1u : 0u;
     f_over[i] = km > 0 && !small ? 1u : 0u;
     k_over[i] = km > 0 && !small ? km : 0u;
+    k_small[i] = km > 0 && small ? km : 0u;
 }
 
 __global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
                                                               const u32 *__restrict__ p_small, const u32 *__restrict__ p_over,
-                                                              const u32 *__restrict__ kb_over, u32 *__restrict__ list_small,
+                                                              const u32 *__restrict__ kb_over, const u32 *__restrict__ kb_small,
+                                                              u32 *__restrict__ list_small, u32 *__restrict__ off_small,
                                                               Node *__restrict__ over_nodes, u32 *__restrict__ over_kbase)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1115,30 +1123,34 @@ __global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__rest
     const Node nd = fin[i];
     const u32 km = nd.child_base;
     const bool small = km <= cap && nd.len <= (u32)SKC_MAXREC && nd.chunk_base <= (u32)SKC_MAXQ;
-    if (km > 0 && small)
+    if (km > 0 && small) {
         list_small[p_small[i]] = i;
+        off_small[p_small[i]] = kb_small[i];
+    }
     if (km > 0 && !small) {
         over_nodes[p_over[i]] = nd;
         over_kbase[p_over[i]] = kb_over[i];
     }
 }
 
-hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, hipStream_t s)
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, u32 *k_small,
+                                  hipStream_t s)
 {
     if (n_fin == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_select_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, f_small, f_over,
-                       k_over);
+                       k_over, k_small);
     return hipGetLastError();
 }
 
 hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
-                                  u32 *list_small, Node *over_nodes, u32 *over_kbase, hipStream_t s)
+                                  const u32 *kb_small, u32 *list_small, u32 *off_small, Node *over_nodes, u32 *over_kbase,
+                                  hipStream_t s)
 {
     if (n_fin == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_select_lists_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, p_small, p_over,
-                       kb_over, list_small, over_nodes, over_kbase);
+                       kb_over, kb_small, list_small, off_small, over_nodes, over_kbase);
     return hipGetLastError();
 }
 

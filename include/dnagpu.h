@@ -190,7 +190,13 @@ int dnagpu_count_keys_in_range(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, 
 
 uint64_t dnagpu_hist_distinct(const dnagpu_hist *h);   /* count(*) over groups                   */
 uint64_t dnagpu_hist_total(const dnagpu_hist *h);      /* sum(count)                              */
+/* The groups in device memory, in the order they were produced (NOT ascending: see dnagpu_hist_download /
+ * dnagpu_hist_sorted_view for that).  An ordered histogram stores its dnagpu_hist_distinct groups back to back.  An
+ * unordered one (dnagpu_hist_is_sorted == 0) stores them bucket by bucket over dnagpu_hist_extent slots, and a
+ * bucket that held copies of a k-mer is followed by padding slots whose COUNT IS 0 (their keys are undefined): skip
+ * them. */
 const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h);
+uint64_t dnagpu_hist_extent(const dnagpu_hist *h);     /* slots of the two device arrays in use (>= distinct) */
 /* counts are 32-bit in device memory (one call covers at most 2^32 - 1 rows); dnagpu_hist_download
  * widens them to the 64-bit count(*) of SQL */
 const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h);

@@ -609,6 +609,18 @@ def check_hist_unordered(hist, ok, oc, what):
     assert_same(gk[order], ok, what + " keys")
     assert_same(gc[order], oc, what + " counts")
     assert hist.summary() == orc.hist_summary(ok, oc), what + " summary"
+    # the raw device arrays (dnagpu_hist_device_keys / _counts over dnagpu_hist_extent slots): the slots whose count is
+    # not 0 are exactly the groups (an unordered histogram pads the range of a bucket that held copies)
+    ext = hist.extent
+    assert ext >= hist.distinct
+    if 0 < ext <= 50_000_000:
+        rk = hist.ctx.download_u64(hist.device_keys, ext)
+        rc = hist.ctx.download_u64(hist.device_counts, (ext + 1) // 2).view(np.uint32)[:ext]
+        keep = rc != 0
+        assert int(keep.sum()) == hist.distinct, f"{what}: {int(keep.sum())} non-padding slots, {hist.distinct} groups"
+        o2 = np.argsort(rk[keep], kind="stable")
+        assert_same(rk[keep][o2], ok, what + " raw keys")
+        assert_same(rc[keep][o2].astype(np.uint64), oc, what + " raw counts")
 
 
 @pytest.mark.parametrize("n,k,first", [(5_000_011, 31, 0), (4_500_000, 32, 0), (6_000_000, 27, 7), (5_000_000, 23, 33),
