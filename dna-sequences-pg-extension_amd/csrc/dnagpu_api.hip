@@ -1238,7 +1238,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 // DNAGPU_SK_SKEWED: a bucket is too heavy (low-complexity input): the caller counts with the ordinary tree
 // instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
-constexpr u64 SK_LEAF_MEAN = 2900;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
+constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
 constexpr u64 SK_MID_LIMIT = 8 * 16 * SK_LEAF_MEAN;  // a mid bucket (planned: 16 x SK_LEAF_MEAN k-mers) eight times over is "heavy"
 
 struct SkLevel {                                 // what one forced partition level leaves behind

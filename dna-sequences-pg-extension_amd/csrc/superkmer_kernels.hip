@@ -847,7 +847,7 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   the waves); a binary search over the prefix instead of the owner table (19.6 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
-constexpr int SKC_SLOTS = 212 * 64;              // 13568 four-byte slots (load 0.24 at 3300 keys): with the tables below 79.2 KiB, two workgroups per CU
+constexpr int SKC_SLOTS = 236 * 64;              // 15104 four-byte slots (load 0.2 at 3000 keys): with the tables below 79.0 KiB, two workgroups per CU
 constexpr int SKC_MAXREC = 512;                  // records of a bucket (a bucket of 3300 k-mers of random sequence has ~370)
 constexpr int SKC_KPT = 4;                       // k-mers per quad
 constexpr int SKC_MAXQ = SKC_NT;                 // quads of a bucket: one per thread (the selection sends buckets with more elsewhere)
