@@ -1689,10 +1689,11 @@ static bool dense_pays(u64 n, int k)
 
 // any_order: the caller does not need ascending keys across the whole result (dnagpu_count_kmers_unordered): long
 // k-mers of long sequences then go through the super-k-mer engine
-constexpr u64 SK_MIN_ROWS = (u64)1 << 22;
-// the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record): measured at 1 Gbase, k = 27 is 5 %
-// slower than the tree, k = 31 4 % faster (10 % at 3 Gbase)
-constexpr int SK_MIN_K = 29;
+constexpr u64 SK_MIN_ROWS = (u64)1 << 25;
+// the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record) and the sequence is: measured at
+// 1 Gbase, tree vs this engine: k = 23 13.2 vs 16.9 ms, 24 13.1 vs 13.2, 25 13.2 vs 12.0, 27 13.2 vs 11.5, 29 13.0 vs 10.8;
+// k = 31: 16 Mbase 0.63 vs 0.63 ms, 64 Mbase 1.32 vs 1.11, 250 Mbase 3.70 vs 3.21, 3 Gbase 42.0 vs 30.5
+constexpr int SK_MIN_K = 25;
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
                       bool any_order = false)
