@@ -936,13 +936,12 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         }
     };
 
-    for (;;) {
-        const u32 lq_next = lq + gridDim.x;
-        const bool has_next = lq_next < n_list;
-        const u32 ln = has_next ? list[lq_next] : li;
-        const u32 off_next = has_next ? list_off[lq_next] : off;
-        const Node nn = fin[ln];
-        // ---- records into LDS; prefix over their quad counts (record threads only)
+    // Two barriers per bucket.  The bucket's records and owner table are staged (registers -> LDS) right behind the
+    // previous bucket's barrier B, from records requested a bucket earlier and a quad prefix the record waves computed
+    // at the end of the previous insert phase; descriptors run two buckets ahead.
+    const u32 step = gridDim.x;
+    u32 n_quads = 0;
+    {   // the first bucket: staged here (one extra barrier)
         const u32 len = (u32)tid < nd.len ? (u32)((myrec.y >> 44) & 31) + 1u : 0u;
         const u32 nq = (len + SKC_KPT - 1) / SKC_KPT;
         u32 qinc = 0;
@@ -952,24 +951,29 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             if (lane == 63)
                 wq[wave] = qinc;
         }
-        __syncthreads();                           // A (also: every slot claimed for the previous bucket has been reset)
-        u32 n_quads = 0;
-        {
-            u32 qb = 0;
-            sk_wave_prefix16(wq, RWAVES, wave, lane, qb, n_quads);
-            if (tid < SKC_MAXREC) {
-                const u32 q0 = qb + qinc - nq;
-                for (u32 q = 0; q < nq; q++)
-                    ownq[q0 + q] = (unsigned short)((u32)tid | (q << 9));
-            }
+        __syncthreads();
+        u32 qb = 0;
+        sk_wave_prefix16(wq, RWAVES, wave, lane, qb, n_quads);
+        if (tid < SKC_MAXREC) {
+            const u32 q0 = qb + qinc - nq;
+            for (u32 q = 0; q < nq; q++)
+                ownq[q0 + q] = (unsigned short)((u32)tid | (q << 9));
         }
-        // the next bucket's records: in flight from here on
-        if (has_next) {
-            myrec.x = myrec.y = 0;
-            if ((u32)tid < nn.len)
-                myrec = recs[(u64)nn.start + tid];
-        }
-        __syncthreads();                           // A2: lrec[] and ownq[] complete
+    }
+    bool has_next = lq + step < n_list;
+    u32 ln = has_next ? list[lq + step] : li;
+    u32 off_next = has_next ? list_off[lq + step] : off;
+    Node nn = fin[ln];
+    myrec.x = myrec.y = 0;
+    if (has_next && (u32)tid < nn.len)
+        myrec = recs[(u64)nn.start + tid];         // the second bucket's records: in flight
+    for (;;) {
+        const u32 lq2 = lq + 2 * step;
+        const bool has_next2 = lq2 < n_list;
+        const u32 ln2 = has_next2 ? list[lq2] : ln;                     // (used at the end of this iteration)
+        const u32 off2 = has_next2 ? list_off[lq2] : off_next;
+        const Node nn2 = fin[ln2];
+        __syncthreads();                           // A2: lrec[] and ownq[] complete, every slot of the previous bucket reset
         // ---- this thread's quad
         u64 ck[KEEP];
         u32 cslot[KEEP];
@@ -1029,10 +1033,19 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u32 wc = wave_sum((u32)__popc(c_mask));
         if (lane == 0)
             wclaim[par][wave] = wc;
+        // the next bucket's quad prefix (record waves; its records were requested a bucket ago)
+        const u32 len_n = has_next && (u32)tid < nn.len ? (u32)((myrec.y >> 44) & 31) + 1u : 0u;
+        const u32 nq_n = (len_n + SKC_KPT - 1) / SKC_KPT;
+        u32 qinc_n = 0;
+        if (tid < SKC_MAXREC) {
+            qinc_n = wave_incl_scan(nq_n);
+            if (lane == 63)
+                wq[wave] = qinc_n;
+        }
         __syncthreads();                           // B: all inserts done
         if (have_prev)
             emit_prev();                           // (a bucket behind: its stores overlap this bucket's tail and the next one's head)
-        // ---- this bucket: counts of the claimed slots, table cleaned, output range requested; emitted next round
+        // ---- this bucket: counts of the claimed slots, table cleaned; emitted next round
         u32 before = 0, D = 0;
         sk_wave_prefix16(wclaim[par], WAVES, wave, lane, before, D);
         const bool any_copy = copy_seen[par] != 0; // (random sequence: no bucket has one, and the copy counters are not read)
@@ -1066,10 +1079,28 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         par ^= 1;
         if (!has_next)
             break;
-        lq = lq_next;
+        // ---- the next bucket is staged (nobody reads lrec / ownq between B and A2), the one after it requested
+        {
+            u32 qb = 0;
+            sk_wave_prefix16(wq, RWAVES, wave, lane, qb, n_quads);
+            if (tid < SKC_MAXREC) {
+                lrec[tid] = myrec;
+                const u32 q0 = qb + qinc_n - nq_n;
+                for (u32 q = 0; q < nq_n; q++)
+                    ownq[q0 + q] = (unsigned short)((u32)tid | (q << 9));
+            }
+            myrec.x = myrec.y = 0;
+            if (has_next2 && (u32)tid < nn2.len)
+                myrec = recs[(u64)nn2.start + tid];
+        }
+        lq += step;
         li = ln;
         off = off_next;
         nd = nn;
+        has_next = has_next2;
+        ln = ln2;
+        off_next = off2;
+        nn = nn2;
     }
     emit_prev();                                   // the last bucket's output
     if (tid == 0)
