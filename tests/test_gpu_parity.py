@@ -863,6 +863,51 @@ def test_records_exchange_one_process(ctx, pkg, world, n, k, motif):
         ctx.count_records([(0, 5, n_buckets)], k, rows)          # a bucket the geometry does not have
 
 
+def test_count_records_fingerprint_collisions(ctx, pkg):
+    """sk_count's table slots hold a 20-bit fingerprint, not the key: keys that share slot AND fingerprint must still be
+    told apart (the claimant's key is re-derived from the staged records and compared in full).  Hand-made records of
+    one k-mer each, all in one final bucket: key ^ (m | m << 32) for m < 128 leaves both the slot hash
+    (a function of lo ^ hi) and the fingerprint (that, xor bits 39.. of the key) unchanged -- 128 distinct keys on one
+    probe chain with one fingerprint -- some of them several times, mixed with random keys."""
+    k, rows = 31, 50_000_000                       # (rows only fixes the bucket geometry)
+    nb = ctx.sk_buckets(rows, k)
+    rng = np.random.default_rng(7)
+    kmask = (1 << (2 * k)) - 1
+    base = int(rng.integers(0, 1 << 62)) & kmask & ~((127 << 32) | 127)
+    fam = [base ^ (m | (m << 32)) for m in range(128)]
+    keys = list(fam)                               # at most 512 records, so that the bucket is sk_count's (not the tree's)
+    for i, kv in enumerate(fam[:60]):
+        keys += [kv] * (1 + i % 3)                 # copies
+    keys += [int(x) & kmask for x in rng.integers(0, 1 << 62, 200)]
+    keys = np.array(keys, dtype=np.uint64)
+    assert len(keys) <= 512
+    rng.shuffle(keys)
+    d1, d2, bucket = 5, 3, nb - 1
+    recs = np.empty(2 * len(keys), dtype=np.uint64)
+    recs[0::2] = keys                              # lo: the k-mer's 31 bases; hi: no more bases, len - 1 = 0
+    recs[1::2] = np.uint64((d1 << 49) | (d2 << 59))
+    buf = ctx.buffer_alloc(recs.nbytes)
+    ctx.upload_u64(buf, recs)
+    h = ctx.count_records([(buf, len(keys), bucket)], k, rows)
+    ok, oc = np.unique(keys, return_counts=True)
+    assert h.total == len(keys)
+    check_hist_unordered(h, ok, oc.astype(np.uint64), "crafted fingerprint family")
+    assert h.extent == len(keys)                   # sk_count's placement: one slot per k-mer, copies leave padding
+    h.free()
+    # the same keys as 3 x more records than sk_count takes: the expansion + hashed-leaves path
+    big = np.concatenate([keys, keys, keys, keys])
+    recs = np.empty(2 * len(big), dtype=np.uint64)
+    recs[0::2] = big
+    recs[1::2] = np.uint64((d1 << 49) | (d2 << 59))
+    buf2 = ctx.buffer_alloc(recs.nbytes)
+    ctx.upload_u64(buf2, recs)
+    h = ctx.count_records([(buf2, len(big), bucket)], k, rows)
+    check_hist_unordered(h, ok, (4 * oc).astype(np.uint64), "crafted fingerprint family, oversize bucket")
+    h.free()
+    ctx.buffer_free(buf2)
+    ctx.buffer_free(buf)
+
+
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
