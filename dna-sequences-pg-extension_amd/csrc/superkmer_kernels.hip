@@ -704,7 +704,7 @@ hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const 
 constexpr int SKR_NT = 1024;
 constexpr int SKR_ITEMS = 8;
 constexpr int SKR_TILE = SKR_NT * SKR_ITEMS;
-__global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restrict__ mids, u32 n_mids,
+__global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__restrict__ mids, u32 n_mids,
                                                             const ull2_t *__restrict__ src_all, ull2_t *__restrict__ dst_all,
                                                             Node *__restrict__ out_nodes)
 {
@@ -722,14 +722,39 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
         (&kc[0][0])[q] = 0;
         (&qc[0][0])[q] = 0;
     }
+    if (tid < 17)
+        tcnt[tid] = 0;
     __syncthreads();
-    for (u32 r = tid; r < nd.len; r += SKR_NT) {
-        const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
-        const u32 d2 = (u32)(m >> 59) & 15u;
-        const u32 len = (u32)((m >> 44) & 31) + 1u;
-        atomicAdd(&rc[lane][d2], 1u);
-        atomicAdd(&kc[lane][d2], len);
-        atomicAdd(&qc[lane][d2], (len + 3u) >> 2);   // quads of sk_count: groups of four k-mers of one record
+    // A mid bucket of at most one tile (the planned size is ~5,000 records): its digit words are read ONCE -- counted
+    // for the output nodes and ranked for the copy in the same sweep.
+    const bool one_tile = nd.len <= (u32)SKR_TILE;
+    u32 dig1[SKR_ITEMS], rank1[SKR_ITEMS];
+    if (one_tile) {
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 r = tid + j * SKR_NT;
+            dig1[j] = 0;
+            rank1[j] = 0;
+            if (r < nd.len) {
+                const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
+                const u32 d2 = (u32)(m >> 59) & 15u;
+                const u32 len = (u32)((m >> 44) & 31) + 1u;
+                atomicAdd(&rc[lane][d2], 1u);
+                atomicAdd(&kc[lane][d2], len);
+                atomicAdd(&qc[lane][d2], (len + 3u) >> 2);
+                dig1[j] = d2;
+                rank1[j] = atomicAdd(&tcnt[d2], 1u);
+            }
+        }
+    } else {
+        for (u32 r = tid; r < nd.len; r += SKR_NT) {
+            const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
+            const u32 d2 = (u32)(m >> 59) & 15u;
+            const u32 len = (u32)((m >> 44) & 31) + 1u;
+            atomicAdd(&rc[lane][d2], 1u);
+            atomicAdd(&kc[lane][d2], len);
+            atomicAdd(&qc[lane][d2], (len + 3u) >> 2);   // quads of sk_count: groups of four k-mers of one record
+        }
     }
     __syncthreads();
     if (tid < 48) {                                // threads 0..15: records, 16..31: k-mers, 32..47: quads of d2 = tid % 16
@@ -737,7 +762,6 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
         u32 sum = 0;
         for (int q = 0; q < 64; q++)
             sum += tab[q][tid & 15];
-        tcnt[tid & 15] = 0;                        // (benign: all three store 0)
         if (tid < 16)
             rc[0][tid] = sum;
         else if (tid < 32)
@@ -759,10 +783,33 @@ __global__ __launch_bounds__(SKR_NT) void sk_regroup_kernel(const Node *__restri
             o.child_base = kc[0][j];
             o.chunk_base = qc[0][j];
             out_nodes[(u64)i * 16 + j] = o;
+            if (one_tile)
+                tcnt[j] = run;                     // the tile's digit offsets (its counts are the bucket's)
             run += rc[0][j];
         }
+        if (one_tile)
+            tcnt[16] = run;
     }
     __syncthreads();
+    if (one_tile) {
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 r = tid + j * SKR_NT;
+            if (r < nd.len)
+                idx[tcnt[dig1[j]] + rank1[j]] = (unsigned short)r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 s2 = tid + j * SKR_NT;
+            if (s2 < nd.len) {
+                const ull2_t r = src[idx[s2]];
+                const u32 d = (u32)(r.y >> 59) & 15u;
+                __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s2 - tcnt[d])]);
+            }
+        }
+        return;
+    }
     for (u32 t0 = 0; t0 < nd.len; t0 += SKR_TILE) {
         const u32 n_tile = nd.len - t0 < (u32)SKR_TILE ? nd.len - t0 : (u32)SKR_TILE;
         u32 dig[SKR_ITEMS], rank[SKR_ITEMS];
