@@ -176,7 +176,7 @@ def main():
         state = {"chunk": None}
         # long k-mers, any group order (the single-GPU default's rule): every rank cuts the super-k-mer records of its own
         # rows, the coarse buckets travel to their owners (one all-to-all of 1.8 B per k-mer), the owners count them
-        use_records = args.engine != "tree" and k >= 25
+        use_records = args.engine != "tree" and k >= 23
         extra["exchange"] = ("records: own rows -> super-k-mer records -> all-to-all by coarse bucket -> count" if use_records else
                              "sequence: all-gather of the packed chunks -> every rank counts the key range it owns")
 

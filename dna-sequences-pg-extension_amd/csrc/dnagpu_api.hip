@@ -1295,10 +1295,13 @@ struct SkGeom {
     u32 c0n;
     u64 mid_limit;
 };
-static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n)
+static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n, int k)
 {
     SkGeom g;
-    const u64 n_final = std::max<u64>(n / SK_LEAF_MEAN, 16);
+    // short k-mers have short runs ((k - 13) / 2 k-mers per record on random sequence): the buckets shrink with them so that
+    // a bucket's records (~450) still fit sk_count's 512-record stage
+    const u64 leaf_mean = std::min<u64>(SK_LEAF_MEAN, 225 * (u64)(k - 13));
+    const u64 n_final = std::max<u64>(n / leaf_mean, 16);
     const u64 n_mid = (n_final + 15) / 16;
     g.b1 = 1;
     while (g.b1 < MAX_SPLIT_BITS && ((u64)1 << g.b1) < n_mid)
@@ -1457,7 +1460,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
 static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, dnagpu_hist *h)
 {
     PoolScope ps(ctx);
-    const SkGeom g = sk_geometry(ctx, n);
+    const SkGeom g = sk_geometry(ctx, n, k);
     void *rec0 = nullptr, *recs = nullptr;
     Node *coarse = nullptr, *fin = nullptr;
     u32 n_coarse = 0, n_fin = 0;
@@ -1479,7 +1482,7 @@ static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u6
 {
     hipStream_t st = ctx->stream;
     PoolScope ps(ctx);
-    const SkGeom g = sk_geometry(ctx, global_rows);
+    const SkGeom g = sk_geometry(ctx, global_rows, k);
     const u32 n_coarse = 1u << g.r0bits;
     std::vector<u64> blen(n_coarse, 0), boff(n_coarse + 1, 0);
     for (u32 i = 0; i < n_pieces; i++) {
@@ -1691,9 +1694,9 @@ static bool dense_pays(u64 n, int k)
 // k-mers of long sequences then go through the super-k-mer engine
 constexpr u64 SK_MIN_ROWS = (u64)1 << 25;
 // the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record) and the sequence is: measured at
-// 1 Gbase, tree vs this engine: k = 23 13.2 vs 16.9 ms, 24 13.1 vs 13.2, 25 13.2 vs 12.0, 27 13.2 vs 11.5, 29 13.0 vs 10.8;
+// 1 Gbase, tree vs this engine: k = 23 13.4 vs 13.1 ms, 24 13.2 vs 12.4, 25 13.2 vs 12.0, 27 13.2 vs 11.5, 29 13.0 vs 10.8;
 // k = 31: 16 Mbase 0.63 vs 0.63 ms, 64 Mbase 1.32 vs 1.11, 250 Mbase 3.70 vs 3.21, 3 Gbase 42.0 vs 30.5
-constexpr int SK_MIN_K = 25;
+constexpr int SK_MIN_K = 23;
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
                       bool any_order = false)
@@ -1900,7 +1903,7 @@ extern "C" int dnagpu_sk_buckets(const dnagpu_ctx *ctx, uint64_t global_rows, in
 {
     if (!ctx || k < sk_min_k() || k > 32 || global_rows == 0 || global_rows > 0xFFFFFFFFull)
         return 0;
-    return (int)sk_geometry(ctx, global_rows).c0n;
+    return (int)sk_geometry(ctx, global_rows, k).c0n;
 }
 
 extern "C" int dnagpu_sk_records(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, uint64_t first, uint64_t count,
@@ -1911,7 +1914,7 @@ extern "C" int dnagpu_sk_records(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, 
         return DNAGPU_ERR_BAD_ARG;
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
-    const SkGeom g = sk_geometry(ctx, global_rows);
+    const SkGeom g = sk_geometry(ctx, global_rows, k);
     dnagpu_records *r = new (std::nothrow) dnagpu_records();
     if (!r)
         return DNAGPU_ERR_OOM;

@@ -643,7 +643,7 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     assert h.total == len(keys)
     check_hist_unordered(h, ok, oc, f"unordered n={n} k={k} first={first}")
     h.free()
-    if k >= 25 and len(keys) >= (1 << 25):           # the default choice of engine
+    if k >= 23 and len(keys) >= (1 << 25):           # the default choice of engine
         h = ctx.count_kmers_unordered(d, k, first=first)
         assert not h.is_sorted
         assert h.summary() == orc.hist_summary(ok, oc)
