@@ -121,3 +121,15 @@ def test_sharded_count_rccl_one_rank(tmp_path, mode):
     host two RCCL ranks)."""
     res = run_world("gpu", 1, 2_000_000, 31, tmp_path, 29561 + (1 if mode == "keys" else 0), mode, backend="nccl")
     assert res["ok"] and res["sorted"], res
+
+
+@pytest.mark.gpu
+def test_pool_buffer_on_another_stream(tmp_path):
+    """include/dnagpu.h's stream rule for pooled buffers, exercised from a non-default torch stream (own process: torch
+    brings its own ROCm runtime)"""
+    out = tmp_path / "stream.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stream_worker.py"), str(out)],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
+    assert p.returncode == 0
+    res = json.loads(out.read_text())
+    assert res["ok"], res
