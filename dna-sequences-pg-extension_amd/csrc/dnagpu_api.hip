@@ -1239,7 +1239,11 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 // instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
 constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
-constexpr u64 SK_MID_LIMIT = 8 * 16 * SK_LEAF_MEAN;  // a mid bucket (planned: 16 x SK_LEAF_MEAN k-mers) eight times over is "heavy"
+// A mid bucket of more than SK_MID_LIMIT k-mers (planned: 16 x SK_LEAF_MEAN) is "heavy" and leaves the record path for the
+// expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
+// few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
+constexpr u64 SK_MID_LIMIT = (u64)1 << 22;
+constexpr u64 SK_BIG_LIMIT = (u64)1 << 22;
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;
@@ -1548,38 +1552,34 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     const u32 n_heavy = heavy.n;
     prof_mark(ctx, "sk_select");
     const u32 cap = (u32)sk_count_cap();
-    u32 *f_small = nullptr, *f_over = nullptr, *k_over = nullptr, *k_small = nullptr, *scan_tmp = nullptr, *totals = nullptr,
-        *list_small = nullptr, *off_small = nullptr;
+    const u32 big_limit = (u32)SK_BIG_LIMIT;
+    u32 *f_small = nullptr, *f_big = nullptr, *f_over = nullptr, *f_over_raw = nullptr, *k_over = nullptr, *k_range = nullptr,
+        *scan_tmp = nullptr, *totals = nullptr, *list_small = nullptr, *off_small = nullptr, *list_big = nullptr, *off_big = nullptr;
     RC_TRY(ps.alloc((size_t)n_fin, &f_small));
-    RC_TRY(ps.alloc((size_t)n_fin, &f_over));
-    RC_TRY(ps.alloc((size_t)n_fin, &k_over));
-    RC_TRY(ps.alloc((size_t)n_fin, &k_small));
+    RC_TRY(ps.alloc((size_t)n_fin, &f_big));
+    RC_TRY(ps.alloc((size_t)n_fin, &k_range));
     RC_TRY(ps.alloc((size_t)scan_tmp_words(n_fin), &scan_tmp));
-    RC_TRY(ps.alloc(4, &totals));
+    RC_TRY(ps.alloc(8, &totals));
     RC_TRY(ps.alloc((size_t)n_fin, &list_small));
     RC_TRY(ps.alloc((size_t)n_fin, &off_small));
-    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, f_small, f_over, k_over, k_small, st));
+    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, big_limit, f_small, f_big, k_range, st));
     HIP_TRY(launch_scan_u32(f_small, f_small, n_fin, scan_tmp, totals + 0, st));
-    HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 1, st));
-    HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 2, st));
-    HIP_TRY(launch_scan_u32(k_small, k_small, n_fin, scan_tmp, totals + 3, st));
-    u32 ht[4] = {0, 0, 0, 0};
+    HIP_TRY(launch_scan_u32(f_big, f_big, n_fin, scan_tmp, totals + 1, st));
+    HIP_TRY(launch_scan_u32(k_range, k_range, n_fin, scan_tmp, totals + 2, st));
+    u32 ht[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ht, totals, sizeof ht, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const u32 n_small = ht[0], n_over = ht[1];
-    const u64 over_keys = ht[2];
-    const u64 small_keys = ht[3];                // the output slots sk_count's buckets take: one per k-mer, in list order
-    Node *over_nodes = nullptr;
-    u32 *over_kbase = nullptr;
-    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_nodes));
-    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_kbase));
-    HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, f_small, f_over, k_over, k_small, list_small, off_small, over_nodes, over_kbase, st));
+    const u32 n_small = ht[0], n_big = ht[1];
+    const u64 small_keys = ht[2];                // the output slots of the small and big buckets: one per k-mer, in bucket order
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &list_big));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &off_big));
+    HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, big_limit, f_small, f_big, k_range, list_small, off_small, list_big, off_big, st));
 
     // output arrays and the segment directory: final buckets first, the nodes of the oversize buckets' tree behind them
     u64 *cursor = nullptr, *ok = nullptr;
     u32 *oc = nullptr;
-    // [0] next free output slot of the leaves behind sk_count's ranges; [1] buckets whose expansion disagrees with the
-    // partition's count; [2] groups sk_count wrote
+    // [0] next free output slot of the leaves behind the buckets' ranges; [1] buckets whose expansion disagrees with the
+    // partition's count; [2] groups sk_count and sk_count_big wrote
     RC_TRY(ps.alloc(3, &cursor));
     RC_TRY(ps.alloc((size_t)n, &ok));
     RC_TRY(ps.alloc((size_t)n, &oc));
@@ -1588,10 +1588,41 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
         HIP_TRY(hipMemcpyAsync(cursor, init, sizeof init, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));       // (init is a stack variable)
     }
-    TreeResult tr;
-    memset(&tr, 0, sizeof tr);
     u64 *seg_off = nullptr;
     u32 *seg_cnt = nullptr;
+    // (the directory of the final buckets; the tree's nodes get a second one behind it once their number is known)
+    u64 *seg_off_fin = nullptr;
+    u32 *seg_cnt_fin = nullptr;
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_fin, 1), &seg_off_fin));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_fin, 1), &seg_cnt_fin));
+    HIP_TRY(hipMemsetAsync(seg_cnt_fin, 0, (size_t)n_fin * sizeof(u32), st));     // empty and expanded buckets: no groups of their own
+    HIP_TRY(hipMemsetAsync(seg_off_fin, 0, (size_t)n_fin * sizeof(u64), st));
+    // ---- long buckets of few distinct keys (repeats): one table per bucket; what outgrows it joins the expansion below
+    u32 *big_status = nullptr;
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &big_status));
+    if (n_big) {
+        prof_mark(ctx, "sk_count_big");
+        HIP_TRY(launch_sk_count_big(fin, list_big, off_big, n_big, recs, k, cursor + 2, seg_off_fin, seg_cnt_fin, ok, oc, big_status, st));
+    }
+    prof_mark(ctx, "sk_select_over");
+    RC_TRY(ps.alloc((size_t)n_fin, &f_over));
+    RC_TRY(ps.alloc((size_t)n_fin, &f_over_raw));
+    RC_TRY(ps.alloc((size_t)n_fin, &k_over));
+    HIP_TRY(launch_sk_over_flags(fin, n_fin, cap, big_limit, f_big, big_status, f_over_raw, k_over, st));
+    HIP_TRY(launch_scan_u32(f_over_raw, f_over, n_fin, scan_tmp, totals + 4, st));
+    HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 5, st));
+    u32 ho[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(ho, totals + 4, sizeof ho, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const u32 n_over = ho[0];
+    const u64 over_keys = ho[1];
+    Node *over_nodes = nullptr;
+    u32 *over_kbase = nullptr;
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_nodes));
+    RC_TRY(ps.alloc((size_t)std::max<u32>(n_over, 1), &over_kbase));
+    HIP_TRY(launch_sk_over_list(fin, n_fin, f_over_raw, f_over, k_over, over_nodes, over_kbase, st));
+    TreeResult tr;
+    memset(&tr, 0, sizeof tr);
     if (n_over + n_heavy > 0) {
         // oversize final buckets (the tail of the size distribution, moderate repeats) and heavy mid buckets (the
         // minimizers of long repeats): keys, then the ordinary levels with their skew paths.  Every such bucket becomes
@@ -1640,8 +1671,8 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     const u32 n_segs = n_fin + tr.n_nodes;
     RC_TRY(ps.alloc((size_t)n_segs, &seg_off));
     RC_TRY(ps.alloc((size_t)n_segs, &seg_cnt));
-    HIP_TRY(hipMemsetAsync(seg_cnt, 0, (size_t)n_fin * sizeof(u32), st));     // empty and oversize buckets: no groups of their own
-    HIP_TRY(hipMemsetAsync(seg_off, 0, (size_t)n_fin * sizeof(u64), st));
+    HIP_TRY(hipMemcpyAsync(seg_cnt, seg_cnt_fin, (size_t)n_fin * sizeof(u32), hipMemcpyDeviceToDevice, st));   // (sk_count_big's entries)
+    HIP_TRY(hipMemcpyAsync(seg_off, seg_off_fin, (size_t)n_fin * sizeof(u64), hipMemcpyDeviceToDevice, st));
     if (tr.n_nodes > 0) {
         u32 *flags = nullptr, *ltmp = nullptr, *cls_list = nullptr;
         RC_TRY(ps.alloc((size_t)tr.n_nodes + 1, &flags));

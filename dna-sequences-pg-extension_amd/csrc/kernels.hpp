@@ -185,11 +185,19 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off
                            u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
 
 int sk_count_cap();       // most k-mers a final bucket may hold to be counted from its records
-hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, u32 *k_small,
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, u32 *f_small, u32 *f_big, u32 *k_range,
                                   hipStream_t s);
-hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
-                                  const u32 *kb_small, u32 *list_small, u32 *off_small, Node *over_nodes, u32 *over_kbase,
-                                  hipStream_t s);
+hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, const u32 *p_small, const u32 *p_big,
+                                  const u32 *kb_range, u32 *list_small, u32 *off_small, u32 *list_big, u32 *off_big, hipStream_t s);
+// buckets that go through the expansion: too many k-mers for sk_count_big, or given up by it (big_status[p] != 0)
+hipError_t launch_sk_over_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, const u32 *p_big, const u32 *big_status,
+                                u32 *f_over, u32 *k_over, hipStream_t s);
+hipError_t launch_sk_over_list(const Node *fin, u32 n_fin, const u32 *f_raw, const u32 *p_over, const u32 *kb_over, Node *over_nodes,
+                               u32 *over_kbase, hipStream_t s);
+// long buckets of few distinct keys (repeats): one workgroup per bucket, one LDS table for the whole bucket; status[i] = 1
+// where the distinct keys outgrew the table (the bucket's range is then all padding)
+hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
+                               u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();

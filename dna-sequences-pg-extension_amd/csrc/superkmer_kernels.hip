@@ -1172,63 +1172,305 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off
 }
 
 // ------------------------------------------------------------------------------------------------
-// selection of the final buckets: those of at most `cap` k-mers are counted from their records (list_small); the
-// others are expanded to keys for the ordinary levels (compact copies in over_nodes, their key ranges in over_kbase)
-__global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
-                                                              u32 *__restrict__ f_small, u32 *__restrict__ f_over,
-                                                              u32 *__restrict__ k_over, u32 *__restrict__ k_small)
+// sk_count_big: final buckets that are too long for sk_count but hold FEW DISTINCT keys -- what repeats make: a
+// minimizer of a repeated stretch brings thousands to millions of copies of a handful of k-mers into one bucket.  One
+// workgroup per bucket sweeps its records tile by tile (512 records) into ONE LDS table that is kept for the whole
+// bucket: 8192 eight-byte key slots with 32-bit counts.  Groups leave once, by a sweep of the table, into the
+// bucket's output range (same placement rule as sk_count: the scan of the buckets' k-mer counts).  A bucket whose
+// distinct keys outgrow the table raises its status: the host sends it through the expansion + tree path instead.
+constexpr int SKB_NT = 1024;
+constexpr int SKB_SLOTS = 8192;
+constexpr int SKB_REC = 512;                     // records per tile
+constexpr int SKB_MAXQ = SKB_REC * 8;            // quads of a tile (a record holds at most 32 k-mers)
+constexpr u32 SKB_ROUND_CAP = SKB_SLOTS - SKB_NT * SKC_KPT - 64;   // a round of inserts (<= 4096 new keys) starts below this
+constexpr u64 SKB_EMPTY = ~(u64)0;
+
+__global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
+                                                              const u32 *__restrict__ list_off, u32 n_list,
+                                                              const ull2_t *__restrict__ recs, int k,
+                                                              unsigned long long *__restrict__ n_groups,
+                                                              u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                              u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
+                                                              u32 *__restrict__ status)
 {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_fin)
-        return;
-    const u32 km = fin[i].child_base;
-    const bool small = km <= cap && fin[i].len <= (u32)SKC_MAXREC && fin[i].chunk_base <= (u32)SKC_MAXQ;
-    f_small[i] = km > 0 && small ? 1u : 0u;
-    f_over[i] = km > 0 && !small ? 1u : 0u;
-    k_over[i] = km > 0 && !small ? km : 0u;
-    k_small[i] = km > 0 && small ? km : 0u;
+    constexpr int WAVES = SKB_NT / 64, RWAVES = SKB_REC / 64;
+    __shared__ __attribute__((aligned(16))) u64 tab[SKB_SLOTS];
+    __shared__ u32 cnt[SKB_SLOTS];
+    __shared__ __attribute__((aligned(16))) ull2_t lrec[SKB_REC];
+    __shared__ unsigned short ownq[SKB_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
+    __shared__ u32 wq[RWAVES], wtot[WAVES], wnew[2][WAVES];
+    __shared__ u32 ones;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 kmask = kmer_mask(k);
+    u64 my_groups = 0;
+    for (u32 lq = blockIdx.x; lq < n_list; lq += gridDim.x) {
+        const u32 li = list[lq];
+        const u64 obase = list_off[lq];
+        const Node nd = fin[li];
+        for (int q = tid; q < SKB_SLOTS; q += SKB_NT) {
+            tab[q] = SKB_EMPTY;
+            cnt[q] = 0;
+        }
+        if (tid == 0)
+            ones = 0;
+        __syncthreads();
+        bool failed = false;
+        u32 distinct = 0, rpar = 0;                // (every thread keeps the same count: no shared counter to race on)
+        for (u32 t0 = 0; t0 < nd.len && !failed; t0 += SKB_REC) {
+            // ---- the tile's records into LDS; prefix over their quad counts
+            u32 nq = 0, qinc = 0;
+            if (tid < SKB_REC) {
+                ull2_t r;
+                r.x = r.y = 0;
+                u32 len = 0;
+                if (t0 + (u32)tid < nd.len) {
+                    r = recs[(u64)nd.start + t0 + tid];
+                    len = (u32)((r.y >> 44) & 31) + 1u;
+                }
+                lrec[tid] = r;
+                nq = (len + SKC_KPT - 1) / SKC_KPT;
+                qinc = wave_incl_scan(nq);
+                if (lane == 63)
+                    wq[wave] = qinc;
+            }
+            __syncthreads();
+            u32 n_quads = 0, qb = 0;
+            sk_wave_prefix16(wq, RWAVES, wave, lane, qb, n_quads);
+            if (tid < SKB_REC) {
+                const u32 q0 = qb + qinc - nq;
+                for (u32 q = 0; q < nq; q++)
+                    ownq[q0 + q] = (unsigned short)((u32)tid | (q << 9));
+            }
+            __syncthreads();
+            // ---- rounds of one quad per thread
+            for (u32 r0 = 0; r0 < n_quads; r0 += SKB_NT) {
+                if (distinct > SKB_ROUND_CAP) {    // the table could fill up inside this round
+                    failed = true;
+                    break;
+                }
+                u32 claimed = 0;
+                const u32 qi = r0 + (u32)tid;
+                if (qi < n_quads) {
+                    const u32 e = ownq[qi];
+                    const ull2_t rec = lrec[e & 511u];
+                    const u32 rl = (u32)((rec.y >> 44) & 31) + 1u;
+                    const u32 j0 = (e >> 9) * SKC_KPT;
+                    const u64 hi44 = rec.y & (((u64)1 << 44) - 1);
+                    u64 slo = funnel(rec.x, hi44, 2 * j0), shi = hi44 >> (2 * j0);
+#pragma unroll
+                    for (int q = 0; q < SKC_KPT; q++) {
+                        if (j0 + (u32)q < rl) {
+                            const u64 kv = slo & kmask;
+                            slo = (slo >> 2) | (shi << 62);
+                            shi >>= 2;
+                            if (kv == SKB_EMPTY) {
+                                atomicAdd(&ones, 1u);
+                            } else {
+                                u32 slot = ((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 19) & (u32)(SKB_SLOTS - 1);
+                                for (;;) {
+                                    const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
+                                                              (unsigned long long)SKB_EMPTY, (unsigned long long)kv);
+                                    if (old == SKB_EMPTY || old == kv) {
+                                        atomicAdd(&cnt[slot], 1u);
+                                        claimed += old == SKB_EMPTY ? 1u : 0u;
+                                        break;
+                                    }
+                                    slot = (slot + 1) & (u32)(SKB_SLOTS - 1);
+                                }
+                            }
+                        }
+                    }
+                }
+                const u32 wc = wave_sum(claimed);
+                if (lane == 0)
+                    wnew[rpar][wave] = wc;
+                __syncthreads();
+                u32 nb = 0, nt = 0;
+                sk_wave_prefix16(wnew[rpar], WAVES, wave, lane, nb, nt);
+                distinct += nt;
+                rpar ^= 1;                         // (the next round writes the other row: slow readers of this one are safe)
+            }
+            __syncthreads();                       // lrec / ownq are rewritten by the next tile
+        }
+        // ---- the bucket's groups: a sweep of the table, eight consecutive slots per thread, compacted wave by wave
+        if (!failed) {
+            u64 myk[8];
+            u32 myc[8], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                myk[j] = tab[tid * 8 + j];
+                myc[j] = cnt[tid * 8 + j];
+                mine += myk[j] != SKB_EMPTY ? 1u : 0u;
+            }
+            const u32 inc = wave_incl_scan(mine);
+            if (lane == 63)
+                wtot[wave] = inc;
+            __syncthreads();
+            u32 before = 0, D = 0;
+            sk_wave_prefix16(wtot, WAVES, wave, lane, before, D);
+            u64 o = obase + before + inc - mine;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (myk[j] != SKB_EMPTY) {
+                    out_keys[o] = myk[j];
+                    out_counts[o] = myc[j];
+                    o++;
+                }
+            const u32 n_ones = ones;
+            if (n_ones && tid == 0) {
+                out_keys[obase + D] = SKB_EMPTY;
+                out_counts[obase + D] = n_ones;
+            }
+            const u32 groups = D + (n_ones ? 1u : 0u);
+            for (u32 i = groups + (u32)tid; i < nd.child_base; i += SKB_NT)
+                out_counts[obase + i] = 0;         // padding: the range is as long as the bucket's k-mers
+            if (tid == 0) {
+                seg_off[li] = obase;
+                seg_cnt[li] = groups;
+                status[lq] = 0;
+                my_groups += groups;
+            }
+        } else {
+            for (u32 i = tid; i < nd.child_base; i += SKB_NT)
+                out_counts[obase + i] = 0;         // the whole range is padding: the bucket is counted elsewhere
+            if (tid == 0) {
+                seg_off[li] = obase;
+                seg_cnt[li] = 0;
+                status[lq] = 1;
+            }
+        }
+        __syncthreads();                           // (tab / cnt / counters are reset by the next bucket)
+    }
+    if (tid == 0 && my_groups)
+        atomicAdd(n_groups, (unsigned long long)my_groups);
 }
 
-__global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap,
-                                                              const u32 *__restrict__ p_small, const u32 *__restrict__ p_over,
-                                                              const u32 *__restrict__ kb_over, const u32 *__restrict__ kb_small,
-                                                              u32 *__restrict__ list_small, u32 *__restrict__ off_small,
-                                                              Node *__restrict__ over_nodes, u32 *__restrict__ over_kbase)
+hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
+                               u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, hipStream_t s)
 {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_fin)
-        return;
-    const Node nd = fin[i];
-    const u32 km = nd.child_base;
-    const bool small = km <= cap && nd.len <= (u32)SKC_MAXREC && nd.chunk_base <= (u32)SKC_MAXQ;
-    if (km > 0 && small) {
-        list_small[p_small[i]] = i;
-        off_small[p_small[i]] = kb_small[i];
-    }
-    if (km > 0 && !small) {
-        over_nodes[p_over[i]] = nd;
-        over_kbase[p_over[i]] = kb_over[i];
-    }
-}
-
-hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 *f_small, u32 *f_over, u32 *k_over, u32 *k_small,
-                                  hipStream_t s)
-{
-    if (n_fin == 0)
+    if (n_list == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_select_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, f_small, f_over,
-                       k_over, k_small);
+    int dev = 0, n_cu = 256, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        n_cu = v;
+    const u32 grid = std::min<u32>(n_list, (u32)n_cu);
+    hipLaunchKernelGGL(sk_count_big_kernel, dim3(grid), dim3(SKB_NT), 0, s, fin, list, list_off, n_list,
+                       reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
+                       out_keys, out_counts, status);
     return hipGetLastError();
 }
 
-hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, const u32 *p_small, const u32 *p_over, const u32 *kb_over,
-                                  const u32 *kb_small, u32 *list_small, u32 *off_small, Node *over_nodes, u32 *over_kbase,
+// ------------------------------------------------------------------------------------------------
+// selection of the final buckets.  class 1 "small": sk_count takes it (k-mers, records and quads within its stage); class 2
+// "big": more than twice sk_count's k-mers and up to big_limit, tried by sk_count_big; class 3 "over": expanded to keys
+// for the ordinary levels.
+__device__ __forceinline__ u32 sk_bucket_class(const Node &nd, u32 cap, u32 big_limit)
+{
+    const u32 km = nd.child_base;
+    if (km == 0)
+        return 0u;
+    if (km <= cap && nd.len <= (u32)SKC_MAXREC && nd.chunk_base <= (u32)SKC_MAXQ)
+        return 1u;
+    // (buckets just over sk_count's stage -- the tail of the size distribution of non-repetitive sequence, mostly distinct
+    // keys -- are cheaper through the expansion: 0.55 against 0.8 ms at 3 Gbase uniform)
+    return km > 2 * cap && km <= big_limit ? 2u : 3u;
+}
+
+// flags (to be scanned in place) and the k-mers that take output slots (small and big buckets: k_range) / key slots (over)
+__global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap, u32 big_limit,
+                                                              u32 *__restrict__ f_small, u32 *__restrict__ f_big,
+                                                              u32 *__restrict__ k_range)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin)
+        return;
+    const u32 c = sk_bucket_class(fin[i], cap, big_limit);
+    f_small[i] = c == 1u ? 1u : 0u;
+    f_big[i] = c == 2u ? 1u : 0u;
+    k_range[i] = c == 1u || c == 2u ? fin[i].child_base : 0u;
+}
+
+__global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap, u32 big_limit,
+                                                              const u32 *__restrict__ p_small, const u32 *__restrict__ p_big,
+                                                              const u32 *__restrict__ kb_range, u32 *__restrict__ list_small,
+                                                              u32 *__restrict__ off_small, u32 *__restrict__ list_big,
+                                                              u32 *__restrict__ off_big)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin)
+        return;
+    const u32 c = sk_bucket_class(fin[i], cap, big_limit);
+    if (c == 1u) {
+        list_small[p_small[i]] = i;
+        off_small[p_small[i]] = kb_range[i];
+    } else if (c == 2u) {
+        list_big[p_big[i]] = i;
+        off_big[p_big[i]] = kb_range[i];
+    }
+}
+
+// the buckets that go through the expansion: class 3, and the big ones sk_count_big gave up on
+__global__ __launch_bounds__(256) void sk_over_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap, u32 big_limit,
+                                                            const u32 *__restrict__ p_big, const u32 *__restrict__ big_status,
+                                                            u32 *__restrict__ f_over, u32 *__restrict__ k_over)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin)
+        return;
+    const u32 c = sk_bucket_class(fin[i], cap, big_limit);
+    const bool over = c == 3u || (c == 2u && big_status[p_big[i]] != 0);
+    f_over[i] = over ? 1u : 0u;
+    k_over[i] = over ? fin[i].child_base : 0u;
+}
+
+__global__ __launch_bounds__(256) void sk_over_list_kernel(const Node *__restrict__ fin, u32 n_fin, const u32 *__restrict__ f_raw,
+                                                           const u32 *__restrict__ p_over, const u32 *__restrict__ kb_over,
+                                                           Node *__restrict__ over_nodes, u32 *__restrict__ over_kbase)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fin || !f_raw[i])
+        return;
+    over_nodes[p_over[i]] = fin[i];
+    over_kbase[p_over[i]] = kb_over[i];
+}
+
+hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, u32 *f_small, u32 *f_big, u32 *k_range,
                                   hipStream_t s)
 {
     if (n_fin == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_select_lists_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, p_small, p_over,
-                       kb_over, kb_small, list_small, off_small, over_nodes, over_kbase);
+    hipLaunchKernelGGL(sk_select_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, big_limit, f_small, f_big,
+                       k_range);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, const u32 *p_small, const u32 *p_big,
+                                  const u32 *kb_range, u32 *list_small, u32 *off_small, u32 *list_big, u32 *off_big, hipStream_t s)
+{
+    if (n_fin == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_select_lists_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, big_limit, p_small, p_big,
+                       kb_range, list_small, off_small, list_big, off_big);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_over_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, const u32 *p_big, const u32 *big_status,
+                                u32 *f_over, u32 *k_over, hipStream_t s)
+{
+    if (n_fin == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_over_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, big_limit, p_big, big_status,
+                       f_over, k_over);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_over_list(const Node *fin, u32 n_fin, const u32 *f_raw, const u32 *p_over, const u32 *kb_over, Node *over_nodes,
+                               u32 *over_kbase, hipStream_t s)
+{
+    if (n_fin == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_over_list_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, f_raw, p_over, kb_over, over_nodes,
+                       over_kbase);
     return hipGetLastError();
 }
 
