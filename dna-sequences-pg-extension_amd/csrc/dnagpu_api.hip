@@ -1242,8 +1242,8 @@ constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final buc
 // A mid bucket of more than SK_MID_LIMIT k-mers (planned: 16 x SK_LEAF_MEAN) is "heavy" and leaves the record path for the
 // expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
 // few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
-constexpr u64 SK_MID_LIMIT = (u64)1 << 22;
-constexpr u64 SK_BIG_LIMIT = (u64)1 << 22;
+constexpr u64 SK_MID_LIMIT = (u64)1 << 24;
+constexpr u64 SK_BIG_LIMIT = (u64)1 << 24;
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;

@@ -1199,6 +1199,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKB_REC];
     __shared__ unsigned short ownq[SKB_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wq[RWAVES], wtot[WAVES], wnew[2][WAVES];
+    __shared__ unsigned short mult[SKB_REC];       // copies a record stands for (0: the record equals its predecessor)
     __shared__ u32 ones;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 kmask = kmer_mask(k);
@@ -1217,18 +1218,34 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
         bool failed = false;
         u32 distinct = 0, rpar = 0;                // (every thread keeps the same count: no shared counter to race on)
         for (u32 t0 = 0; t0 < nd.len && !failed; t0 += SKB_REC) {
-            // ---- the tile's records into LDS; prefix over their quad counts
+            // ---- the tile's records into LDS.  A repeat brings the SAME record again and again (the same stretch of
+            // sequence cut at the same places), and the passes keep source order inside a bucket: a record equal to its
+            // predecessor in the tile is not expanded again -- the first of a run of equal records (runs are cut at wave
+            // boundaries) stands for all of them with a multiplicity.
             u32 nq = 0, qinc = 0;
+            ull2_t myr;
+            myr.x = myr.y = 0;
+            u32 mylen = 0;
             if (tid < SKB_REC) {
-                ull2_t r;
-                r.x = r.y = 0;
-                u32 len = 0;
                 if (t0 + (u32)tid < nd.len) {
-                    r = recs[(u64)nd.start + t0 + tid];
-                    len = (u32)((r.y >> 44) & 31) + 1u;
+                    myr = recs[(u64)nd.start + t0 + tid];
+                    mylen = (u32)((myr.y >> 44) & 31) + 1u;
                 }
-                lrec[tid] = r;
-                nq = (len + SKC_KPT - 1) / SKC_KPT;
+                lrec[tid] = myr;
+            }
+            __syncthreads();
+            if (tid < SKB_REC) {
+                bool head = mylen != 0;
+                if (head && lane != 0) {
+                    const ull2_t prev = lrec[tid - 1];
+                    head = prev.x != myr.x || prev.y != myr.y;
+                }
+                const u64 hm = __ballot(head), vm = __ballot(mylen != 0);
+                // the run of a head: up to the next head, or to the end of the wave's records
+                const u64 later = lane == 63 ? 0 : hm & ~(((u64)2 << lane) - 1);
+                const u32 nxt = later ? (u32)__builtin_ctzll(later) : (u32)__popcll(vm);   // (records of a tile are a prefix of the lanes)
+                mult[tid] = head ? (nxt > (u32)lane ? nxt - (u32)lane : 1u) : 0u;
+                nq = head ? (mylen + SKC_KPT - 1) / SKC_KPT : 0u;
                 qinc = wave_incl_scan(nq);
                 if (lane == 63)
                     wq[wave] = qinc;
@@ -1253,6 +1270,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
                 if (qi < n_quads) {
                     const u32 e = ownq[qi];
                     const ull2_t rec = lrec[e & 511u];
+                    const u32 m = mult[e & 511u];
                     const u32 rl = (u32)((rec.y >> 44) & 31) + 1u;
                     const u32 j0 = (e >> 9) * SKC_KPT;
                     const u64 hi44 = rec.y & (((u64)1 << 44) - 1);
@@ -1264,14 +1282,14 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
                             slo = (slo >> 2) | (shi << 62);
                             shi >>= 2;
                             if (kv == SKB_EMPTY) {
-                                atomicAdd(&ones, 1u);
+                                atomicAdd(&ones, m);
                             } else {
                                 u32 slot = ((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 19) & (u32)(SKB_SLOTS - 1);
                                 for (;;) {
                                     const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]),
                                                               (unsigned long long)SKB_EMPTY, (unsigned long long)kv);
                                     if (old == SKB_EMPTY || old == kv) {
-                                        atomicAdd(&cnt[slot], 1u);
+                                        atomicAdd(&cnt[slot], m);
                                         claimed += old == SKB_EMPTY ? 1u : 0u;
                                         break;
                                     }
