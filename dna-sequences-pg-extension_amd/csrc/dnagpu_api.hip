@@ -1242,8 +1242,9 @@ constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final buc
 // A mid bucket of more than SK_MID_LIMIT k-mers (planned: 16 x SK_LEAF_MEAN) is "heavy" and leaves the record path for the
 // expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
 // few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
-constexpr u64 SK_MID_LIMIT = (u64)1 << 24;
-constexpr u64 SK_BIG_LIMIT = (u64)1 << 24;
+constexpr u64 SK_MID_LIMIT = (u64)1 << 27;
+constexpr u32 SK_MID_RECORDS = 1u << 21;           // (a mid bucket is regrouped by one workgroup: ~250 tiles, twice)
+constexpr u64 SK_BIG_LIMIT = (u64)1 << 30;
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;
@@ -1398,13 +1399,21 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st));
     HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
     // ---- skew check on the k-mers per mid bucket, before their records move (the list is short: host)
-    std::vector<u32> kc(l1.n_next);
+    std::vector<u32> kc(l1.n_next), rcn(l1.n_next);
+    u32 *d_lens = nullptr;
+    RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &d_lens));
+    HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
     HIP_TRY(hipMemcpyAsync(kc.data(), kcount, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(rcn.data(), d_lens, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    // heavy: too many k-mers, or too many records for the one workgroup that regroups a mid bucket (its tiles are serial)
+    const bool forced = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) != 0;
+    auto is_heavy = [&](u32 i) { return kc[i] > mid_limit || (!forced && rcn[i] > SK_MID_RECORDS); };
     u64 run = 0, heaviest = 0;
     for (u32 i = 0; i < l1.n_next; i++) {
         run += kc[i];
-        heaviest = std::max<u64>(heaviest, kc[i]);
+        if (is_heavy(i))
+            heaviest = std::max<u64>(heaviest, std::max<u64>(kc[i], mid_limit + 1));
     }
     if (n != 0 && run != n) {
         set_err("super-k-mer partition lost rows: %llu of %llu", (unsigned long long)run, (unsigned long long)n);
@@ -1416,7 +1425,7 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     std::vector<u32> heavy_idx;
     if (heaviest > mid_limit) {
         for (u32 i = 0; i < l1.n_next; i++)
-            if (kc[i] > mid_limit) {
+            if (is_heavy(i)) {
                 heavy_idx.push_back(i);
                 heavy->total += kc[i];
             }
@@ -1602,7 +1611,27 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &big_status));
     if (n_big) {
         prof_mark(ctx, "sk_count_big");
-        HIP_TRY(launch_sk_count_big(fin, list_big, off_big, n_big, recs, k, cursor + 2, seg_off_fin, seg_cnt_fin, ok, oc, big_status, st));
+        // work items: slices of the buckets' records; a bucket of several slices gets a partial area per slice
+        u32 *nsl = nullptr, *sfirst = nullptr, *mfirst = nullptr, *sl_bucket = nullptr, *sl_idx = nullptr, *part_n = nullptr, *part_cnts = nullptr;
+        u64 *part_keys = nullptr;
+        RC_TRY(ps.alloc((size_t)n_big, &nsl));
+        RC_TRY(ps.alloc((size_t)n_big, &sfirst));
+        RC_TRY(ps.alloc((size_t)n_big, &mfirst));
+        HIP_TRY(launch_sk_big_slices(fin, list_big, n_big, nsl, mfirst, st));
+        HIP_TRY(launch_scan_u32(nsl, sfirst, n_big, scan_tmp, totals + 6, st));
+        HIP_TRY(launch_scan_u32(mfirst, mfirst, n_big, scan_tmp, totals + 7, st));
+        u32 hs[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(hs, totals + 6, sizeof hs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const u32 n_slices = hs[0], n_part = hs[1];
+        RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &sl_bucket));
+        RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &sl_idx));
+        RC_TRY(ps.alloc((size_t)std::max<u32>(n_part, 1), &part_n));
+        RC_TRY(ps.alloc((size_t)std::max<u32>(n_part, 1) * sk_big_partial_slots(), &part_keys));
+        RC_TRY(ps.alloc((size_t)std::max<u32>(n_part, 1) * sk_big_partial_slots(), &part_cnts));
+        HIP_TRY(launch_sk_big_slice_fill(nsl, sfirst, n_big, sl_bucket, sl_idx, st));
+        HIP_TRY(launch_sk_count_big(fin, list_big, off_big, nsl, mfirst, sl_bucket, sl_idx, n_slices, n_big, recs, k, cursor + 2,
+                                    seg_off_fin, seg_cnt_fin, ok, oc, big_status, part_keys, part_cnts, part_n, n_part > 0, st));
     }
     prof_mark(ctx, "sk_select_over");
     RC_TRY(ps.alloc((size_t)n_fin, &f_over));

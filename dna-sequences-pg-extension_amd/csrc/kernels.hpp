@@ -196,8 +196,18 @@ hipError_t launch_sk_over_list(const Node *fin, u32 n_fin, const u32 *f_raw, con
                                u32 *over_kbase, hipStream_t s);
 // long buckets of few distinct keys (repeats): one workgroup per bucket, one LDS table for the whole bucket; status[i] = 1
 // where the distinct keys outgrew the table (the bucket's range is then all padding)
-hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
-                               u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, hipStream_t s);
+// slices of SKB records per big bucket: nsl[p] = its slices, msl[p] = the same if more than one (else 0); after exclusive
+// scans: sl_bucket / sl_idx[first slice of p + j] = (p, j).  Partial areas of sk_big_partial_slots() groups each, one per
+// slice of a sliced bucket (mfirst = scan of msl); part_n[area] = its groups (~0: the slice gave up).
+hipError_t launch_sk_node_lens(const Node *nodes, u32 n, u32 *lens, hipStream_t s);
+u32 sk_big_slice_records();
+u64 sk_big_partial_slots();
+hipError_t launch_sk_big_slices(const Node *fin, const u32 *list, u32 n_list, u32 *nsl, u32 *msl, hipStream_t s);
+hipError_t launch_sk_big_slice_fill(const u32 *nsl_raw, const u32 *sfirst, u32 n_list, u32 *sl_bucket, u32 *sl_idx, hipStream_t s);
+hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, const u32 *nsl, const u32 *mfirst,
+                               const u32 *sl_bucket, const u32 *sl_idx, u32 n_slices, u32 n_list, const void *recs, int k,
+                               u64 *n_groups, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, u64 *part_keys,
+                               u32 *part_cnts, u32 *part_n, bool any_sliced, hipStream_t s);
 
 // scatter-only microbenchmark entry (bench tooling): one level over a key array
 int scatter_tile_keys();

@@ -1185,13 +1185,82 @@ constexpr int SKB_MAXQ = SKB_REC * 8;            // quads of a tile (a record ho
 constexpr u32 SKB_ROUND_CAP = SKB_SLOTS - SKB_NT * SKC_KPT - 64;   // a round of inserts (<= 4096 new keys) starts below this
 constexpr u64 SKB_EMPTY = ~(u64)0;
 
+// the table's groups, compacted: eight consecutive slots per thread, wave by wave; returns the number of groups (a count
+// of the all-ones key, which the table cannot hold, goes last).  All threads of the workgroup call it.
+__device__ __forceinline__ u32 skb_emit(const u64 *tab, const u32 *cnt, u32 n_ones, u32 *wtot, u64 *dst_keys, u32 *dst_counts)
+{
+    constexpr int WAVES = SKB_NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u64 myk[8];
+    u32 myc[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        myk[j] = tab[tid * 8 + j];
+        myc[j] = cnt[tid * 8 + j];
+        mine += myk[j] != SKB_EMPTY ? 1u : 0u;
+    }
+    const u32 inc = wave_incl_scan(mine);
+    if (lane == 63)
+        wtot[wave] = inc;
+    __syncthreads();
+    u32 before = 0, D = 0;
+    sk_wave_prefix16(wtot, WAVES, wave, lane, before, D);
+    u64 o = before + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (myk[j] != SKB_EMPTY) {
+            dst_keys[o] = myk[j];
+            dst_counts[o] = myc[j];
+            o++;
+        }
+    if (n_ones && tid == 0) {
+        dst_keys[D] = SKB_EMPTY;
+        dst_counts[D] = n_ones;
+    }
+    return D + (n_ones ? 1u : 0u);
+}
+
+// Work item = a SLICE of a bucket (SKB_SLICE_REC records): a bucket of one slice is counted and emitted here; a longer
+// one (millions of copies of a few k-mers) is swept by several workgroups at once, each leaving the groups of its slice
+// in a partial area, and sk_big_merge adds the slices' groups up.
+constexpr u32 SKB_SLICE_REC = 128 * SKB_REC;
+constexpr u32 SKB_FAILED = ~0u;
+
+__global__ __launch_bounds__(256) void sk_big_slices_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list, u32 n_list,
+                                                            u32 *__restrict__ nsl, u32 *__restrict__ msl)
+{
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_list)
+        return;
+    const u32 ns = (fin[list[p]].len + SKB_SLICE_REC - 1) / SKB_SLICE_REC;
+    nsl[p] = ns;
+    msl[p] = ns > 1 ? ns : 0u;
+}
+
+__global__ __launch_bounds__(256) void sk_big_slice_fill_kernel(const u32 *__restrict__ nsl_raw, const u32 *__restrict__ sfirst,
+                                                                u32 n_list, u32 *__restrict__ sl_bucket, u32 *__restrict__ sl_idx)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_list)
+        return;
+    const u32 ns = nsl_raw[p], s0 = sfirst[p];
+    for (u32 j = lane; j < ns; j += 64) {
+        sl_bucket[s0 + j] = p;
+        sl_idx[s0 + j] = j;
+    }
+}
+
 __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
-                                                              const u32 *__restrict__ list_off, u32 n_list,
+                                                              const u32 *__restrict__ list_off, const u32 *__restrict__ nsl,
+                                                              const u32 *__restrict__ mfirst, const u32 *__restrict__ sl_bucket,
+                                                              const u32 *__restrict__ sl_idx, u32 n_slices,
                                                               const ull2_t *__restrict__ recs, int k,
                                                               unsigned long long *__restrict__ n_groups,
                                                               u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
                                                               u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
-                                                              u32 *__restrict__ status)
+                                                              u32 *__restrict__ status, u64 *__restrict__ part_keys,
+                                                              u32 *__restrict__ part_cnts, u32 *__restrict__ part_n)
 {
     constexpr int WAVES = SKB_NT / 64, RWAVES = SKB_REC / 64;
     __shared__ __attribute__((aligned(16))) u64 tab[SKB_SLOTS];
@@ -1204,10 +1273,12 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 kmask = kmer_mask(k);
     u64 my_groups = 0;
-    for (u32 lq = blockIdx.x; lq < n_list; lq += gridDim.x) {
+    for (u32 sq = blockIdx.x; sq < n_slices; sq += gridDim.x) {
+        const u32 lq = sl_bucket[sq], sj = sl_idx[sq], ns = nsl[lq];
         const u32 li = list[lq];
         const u64 obase = list_off[lq];
         const Node nd = fin[li];
+        const u32 r_lo = sj * SKB_SLICE_REC, r_hi = nd.len - r_lo < SKB_SLICE_REC ? nd.len : r_lo + SKB_SLICE_REC;
         for (int q = tid; q < SKB_SLOTS; q += SKB_NT) {
             tab[q] = SKB_EMPTY;
             cnt[q] = 0;
@@ -1217,7 +1288,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
         __syncthreads();
         bool failed = false;
         u32 distinct = 0, rpar = 0;                // (every thread keeps the same count: no shared counter to race on)
-        for (u32 t0 = 0; t0 < nd.len && !failed; t0 += SKB_REC) {
+        for (u32 t0 = r_lo; t0 < r_hi && !failed; t0 += SKB_REC) {
             // ---- the tile's records into LDS.  A repeat brings the SAME record again and again (the same stretch of
             // sequence cut at the same places), and the passes keep source order inside a bucket: a record equal to its
             // predecessor in the tile is not expanded again -- the first of a run of equal records (runs are cut at wave
@@ -1227,7 +1298,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
             myr.x = myr.y = 0;
             u32 mylen = 0;
             if (tid < SKB_REC) {
-                if (t0 + (u32)tid < nd.len) {
+                if (t0 + (u32)tid < r_hi) {
                     myr = recs[(u64)nd.start + t0 + tid];
                     mylen = (u32)((myr.y >> 44) & 31) + 1u;
                 }
@@ -1310,71 +1381,194 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
             }
             __syncthreads();                       // lrec / ownq are rewritten by the next tile
         }
-        // ---- the bucket's groups: a sweep of the table, eight consecutive slots per thread, compacted wave by wave
-        if (!failed) {
-            u64 myk[8];
-            u32 myc[8], mine = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                myk[j] = tab[tid * 8 + j];
-                myc[j] = cnt[tid * 8 + j];
-                mine += myk[j] != SKB_EMPTY ? 1u : 0u;
-            }
-            const u32 inc = wave_incl_scan(mine);
-            if (lane == 63)
-                wtot[wave] = inc;
-            __syncthreads();
-            u32 before = 0, D = 0;
-            sk_wave_prefix16(wtot, WAVES, wave, lane, before, D);
-            u64 o = obase + before + inc - mine;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (myk[j] != SKB_EMPTY) {
-                    out_keys[o] = myk[j];
-                    out_counts[o] = myc[j];
-                    o++;
+        if (ns == 1) {
+            // ---- the whole bucket was this slice: its groups go to its output range
+            if (!failed) {
+                const u32 groups = skb_emit(tab, cnt, ones, wtot, out_keys + obase, out_counts + obase);
+                for (u32 i = groups + (u32)tid; i < nd.child_base; i += SKB_NT)
+                    out_counts[obase + i] = 0;     // padding: the range is as long as the bucket's k-mers
+                if (tid == 0) {
+                    seg_off[li] = obase;
+                    seg_cnt[li] = groups;
+                    status[lq] = 0;
+                    my_groups += groups;
                 }
-            const u32 n_ones = ones;
-            if (n_ones && tid == 0) {
-                out_keys[obase + D] = SKB_EMPTY;
-                out_counts[obase + D] = n_ones;
-            }
-            const u32 groups = D + (n_ones ? 1u : 0u);
-            for (u32 i = groups + (u32)tid; i < nd.child_base; i += SKB_NT)
-                out_counts[obase + i] = 0;         // padding: the range is as long as the bucket's k-mers
-            if (tid == 0) {
-                seg_off[li] = obase;
-                seg_cnt[li] = groups;
-                status[lq] = 0;
-                my_groups += groups;
+            } else {
+                for (u32 i = tid; i < nd.child_base; i += SKB_NT)
+                    out_counts[obase + i] = 0;     // the whole range is padding: the bucket is counted elsewhere
+                if (tid == 0) {
+                    seg_off[li] = obase;
+                    seg_cnt[li] = 0;
+                    status[lq] = 1;
+                }
             }
         } else {
-            for (u32 i = tid; i < nd.child_base; i += SKB_NT)
-                out_counts[obase + i] = 0;         // the whole range is padding: the bucket is counted elsewhere
-            if (tid == 0) {
-                seg_off[li] = obase;
-                seg_cnt[li] = 0;
-                status[lq] = 1;
-            }
+            // ---- one slice of several: its groups go to its partial area
+            const u64 pa = (u64)(mfirst[lq] + sj);
+            u32 groups = SKB_FAILED;
+            if (!failed)
+                groups = skb_emit(tab, cnt, ones, wtot, part_keys + pa * SKB_SLOTS, part_cnts + pa * SKB_SLOTS);
+            if (tid == 0)
+                part_n[pa] = groups;
         }
-        __syncthreads();                           // (tab / cnt / counters are reset by the next bucket)
+        __syncthreads();                           // (tab / cnt / counters are reset by the next slice)
     }
     if (tid == 0 && my_groups)
         atomicAdd(n_groups, (unsigned long long)my_groups);
 }
 
-hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
-                               u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, hipStream_t s)
+// the groups of a sliced bucket: the slices' partial groups added up in one table (one workgroup per bucket)
+__global__ __launch_bounds__(SKB_NT) void sk_big_merge_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
+                                                              const u32 *__restrict__ list_off, const u32 *__restrict__ nsl,
+                                                              const u32 *__restrict__ mfirst, u32 n_list,
+                                                              unsigned long long *__restrict__ n_groups,
+                                                              u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                              u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
+                                                              u32 *__restrict__ status, const u64 *__restrict__ part_keys,
+                                                              const u32 *__restrict__ part_cnts, const u32 *__restrict__ part_n)
+{
+    constexpr int WAVES = SKB_NT / 64;
+    __shared__ __attribute__((aligned(16))) u64 tab[SKB_SLOTS];
+    __shared__ u32 cnt[SKB_SLOTS];
+    __shared__ u32 wtot[WAVES], wnew[2][WAVES];
+    __shared__ u32 ones;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 lq = blockIdx.x;
+    if (lq >= n_list)
+        return;
+    const u32 ns = nsl[lq];
+    if (ns <= 1)
+        return;
+    const u32 li = list[lq];
+    const u64 obase = list_off[lq];
+    const Node nd = fin[li];
+    for (int q = tid; q < SKB_SLOTS; q += SKB_NT) {
+        tab[q] = SKB_EMPTY;
+        cnt[q] = 0;
+    }
+    if (tid == 0)
+        ones = 0;
+    __syncthreads();
+    bool failed = false;
+    u32 distinct = 0, rpar = 0;
+    for (u32 j = 0; j < ns && !failed; j++) {
+        const u64 pa = (u64)(mfirst[lq] + j);
+        const u32 n_e = part_n[pa];
+        if (n_e == SKB_FAILED) {
+            failed = true;
+            break;
+        }
+        for (u32 r0 = 0; r0 < n_e; r0 += SKB_NT) {
+            if (distinct > (u32)(SKB_SLOTS - SKB_NT - 64)) {
+                failed = true;
+                break;
+            }
+            u32 claimed = 0;
+            const u32 e = r0 + (u32)tid;
+            if (e < n_e) {
+                const u64 kv = part_keys[pa * SKB_SLOTS + e];
+                const u32 m = part_cnts[pa * SKB_SLOTS + e];
+                if (kv == SKB_EMPTY) {
+                    atomicAdd(&ones, m);
+                } else {
+                    u32 slot = ((((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u) >> 19) & (u32)(SKB_SLOTS - 1);
+                    for (;;) {
+                        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tab[slot]), (unsigned long long)SKB_EMPTY,
+                                                  (unsigned long long)kv);
+                        if (old == SKB_EMPTY || old == kv) {
+                            atomicAdd(&cnt[slot], m);
+                            claimed = old == SKB_EMPTY ? 1u : 0u;
+                            break;
+                        }
+                        slot = (slot + 1) & (u32)(SKB_SLOTS - 1);
+                    }
+                }
+            }
+            const u32 wc = wave_sum(claimed);
+            if (lane == 0)
+                wnew[rpar][wave] = wc;
+            __syncthreads();
+            u32 nb = 0, nt = 0;
+            sk_wave_prefix16(wnew[rpar], WAVES, wave, lane, nb, nt);
+            distinct += nt;
+            rpar ^= 1;
+        }
+    }
+    __syncthreads();
+    if (!failed) {
+        const u32 groups = skb_emit(tab, cnt, ones, wtot, out_keys + obase, out_counts + obase);
+        for (u32 i = groups + (u32)tid; i < nd.child_base; i += SKB_NT)
+            out_counts[obase + i] = 0;
+        if (tid == 0) {
+            seg_off[li] = obase;
+            seg_cnt[li] = groups;
+            status[lq] = 0;
+            atomicAdd(n_groups, (unsigned long long)groups);
+        }
+    } else {
+        for (u32 i = tid; i < nd.child_base; i += SKB_NT)
+            out_counts[obase + i] = 0;
+        if (tid == 0) {
+            seg_off[li] = obase;
+            seg_cnt[li] = 0;
+            status[lq] = 1;
+        }
+    }
+}
+
+u32 sk_big_slice_records() { return SKB_SLICE_REC; }
+u64 sk_big_partial_slots() { return SKB_SLOTS; }
+
+// lens[i] = nodes[i].len (what the host needs of a node list: 4 of its 32 bytes)
+__global__ __launch_bounds__(256) void sk_node_lens_kernel(const Node *__restrict__ nodes, u32 n, u32 *__restrict__ lens)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        lens[i] = nodes[i].len;
+}
+
+hipError_t launch_sk_node_lens(const Node *nodes, u32 n, u32 *lens, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_node_lens_kernel, dim3((n + 255) / 256), dim3(256), 0, s, nodes, n, lens);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_big_slices(const Node *fin, const u32 *list, u32 n_list, u32 *nsl, u32 *msl, hipStream_t s)
 {
     if (n_list == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_big_slices_kernel, dim3((n_list + 255) / 256), dim3(256), 0, s, fin, list, n_list, nsl, msl);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_big_slice_fill(const u32 *nsl_raw, const u32 *sfirst, u32 n_list, u32 *sl_bucket, u32 *sl_idx, hipStream_t s)
+{
+    if (n_list == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_big_slice_fill_kernel, dim3((n_list + 3) / 4), dim3(256), 0, s, nsl_raw, sfirst, n_list, sl_bucket, sl_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_count_big(const Node *fin, const u32 *list, const u32 *list_off, const u32 *nsl, const u32 *mfirst,
+                               const u32 *sl_bucket, const u32 *sl_idx, u32 n_slices, u32 n_list, const void *recs, int k,
+                               u64 *n_groups, u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *status, u64 *part_keys,
+                               u32 *part_cnts, u32 *part_n, bool any_sliced, hipStream_t s)
+{
+    if (n_slices == 0)
         return hipSuccess;
     int dev = 0, n_cu = 256, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
         n_cu = v;
-    const u32 grid = std::min<u32>(n_list, (u32)n_cu);
-    hipLaunchKernelGGL(sk_count_big_kernel, dim3(grid), dim3(SKB_NT), 0, s, fin, list, list_off, n_list,
-                       reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
-                       out_keys, out_counts, status);
+    const u32 grid = std::min<u32>(n_slices, (u32)n_cu);
+    hipLaunchKernelGGL(sk_count_big_kernel, dim3(grid), dim3(SKB_NT), 0, s, fin, list, list_off, nsl, mfirst, sl_bucket, sl_idx,
+                       n_slices, reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off,
+                       seg_cnt, out_keys, out_counts, status, part_keys, part_cnts, part_n);
+    if (any_sliced)
+        hipLaunchKernelGGL(sk_big_merge_kernel, dim3(n_list), dim3(SKB_NT), 0, s, fin, list, list_off, nsl, mfirst, n_list,
+                           reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt, out_keys, out_counts, status,
+                           part_keys, part_cnts, part_n);
     return hipGetLastError();
 }
 
