@@ -22,6 +22,7 @@ ERR_DNA_EMPTY = 11
 ERR_DNA_INVALID_CHAR = 12
 DEBUG_POISON_POOL = 1
 DEBUG_FORCE_SUPERKMER = 2
+DEBUG_HEAVY_EXPAND = 4
 
 FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2

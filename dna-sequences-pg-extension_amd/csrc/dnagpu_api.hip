@@ -1431,7 +1431,9 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
             }
         // a sequence that is mostly repeats (poly-A, satellites over more than half of it) is cheaper through the tree
         // from scratch
-        if (heavy->total * 2 > run || heavy_idx.size() > 4096)
+        // (with DNAGPU_DEBUG_HEAVY_EXPAND, the path of the tests, a sequence that is mostly repeats is cheaper through the
+        // tree from scratch; the chunked split below has no such limit)
+        if (((ctx->debug_flags & DNAGPU_DEBUG_HEAVY_EXPAND) && heavy->total * 2 > run) || heavy_idx.size() > 32768)
             return DNAGPU_SK_SKEWED;
     }
 
@@ -1440,28 +1442,56 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     prof_mark(ctx, "sk_scatter1");
     HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
 
-    if (!heavy_idx.empty()) {
-        // the heavy buckets leave the record path here: copies of their nodes for the expansion, empty nodes in the list
+    const u32 nh = (u32)heavy_idx.size();
+    const bool heavy_expand = (ctx->debug_flags & DNAGPU_DEBUG_HEAVY_EXPAND) != 0;
+    SkLevel lh;
+    memset(&lh, 0, sizeof lh);
+    u32 *kcount2 = nullptr;
+    Node *hnodes = nullptr;
+    if (nh) {
+        // the heavy buckets leave the list here (empty nodes stay behind): one workgroup could not regroup them in time
         u32 *d_idx = nullptr;
-        const u32 nh = (u32)heavy_idx.size();
         RC_TRY(ps.alloc((size_t)nh, &d_idx));
-        RC_TRY(ps.alloc((size_t)nh, &heavy->nodes));
+        RC_TRY(ps.alloc((size_t)nh, &hnodes));
         HIP_TRY(hipMemcpyAsync(d_idx, heavy_idx.data(), (size_t)nh * sizeof(u32), hipMemcpyHostToDevice, st));
-        HIP_TRY(launch_sk_take_heavy(l1.next, d_idx, nh, kcount, heavy->nodes, st));
+        HIP_TRY(launch_sk_take_heavy(l1.next, d_idx, nh, kcount, hnodes, st));
         HIP_TRY(hipStreamSynchronize(st));       // (heavy_idx is a host vector)
-        heavy->n = nh;
-        heavy->recs = rec1;
+        if (heavy_expand) {                      // (tests: the expansion of whole mid buckets)
+            heavy->nodes = hnodes;
+            heavy->n = nh;
+            heavy->recs = rec1;
+        } else {
+            // They are split by d2 with the CHUNKED level kernels instead (many workgroups per bucket: plan, histogram,
+            // prefix, children, scatter rec1 -> rec0 into the range the bucket would have been regrouped into); their
+            // sixteen children join the final buckets, where sk_count_big takes the long ones slice by slice.
+            u64 hrecs = 0;
+            for (u32 i : heavy_idx)
+                hrecs += rcn[i];
+            u64 chunk_h = std::max<u64>(4 * 8192, (hrecs + 4095) / 4096);
+            chunk_h = (chunk_h + 8191) / 8192 * 8192;
+            prof_mark(ctx, "sk_heavy_split");
+            RC_TRY(sk_level_begin(ctx, ps, hnodes, nh, 4, (u32)chunk_h, &lh));
+            RC_TRY(ps.alloc(std::max<u32>(lh.n_next, 1), &kcount2));
+            HIP_TRY(hipMemsetAsync(kcount2, 0, (size_t)std::max<u32>(lh.n_next, 1) * sizeof(u32), st));
+            HIP_TRY(launch_sk_hist1(hnodes, lh.chunks, lh.n_chunks, rec1, lh.hist, kcount2, st, true));
+            HIP_TRY(launch_level_prefix(hnodes, lh.chunks, lh.n_chunks, nh, (u32)chunk_h, lh.hist, lh.tot, st));
+            HIP_TRY(launch_level_children(hnodes, nh, lh.tot, lh.next, nullptr, nullptr, nullptr, 0, st));
+            HIP_TRY(launch_sk_scatter1(hnodes, lh.chunks, lh.n_chunks, rec1, rec0, lh.hist, lh.tot, st, true));
+            heavy->total = 0;                    // (nothing is left for the expansion of mid buckets)
+        }
     }
     // ---- level 2: every mid bucket regrouped by d2 (rec1 -> rec0): 16 final buckets each
     Node *fn = nullptr;
-    RC_TRY(ps.alloc((size_t)l1.n_next * 16, &fn));
+    RC_TRY(ps.alloc((size_t)l1.n_next * 16 + lh.n_next, &fn));
     prof_mark(ctx, "sk_regroup");
     HIP_TRY(launch_sk_regroup(l1.next, l1.n_next, rec1, rec0, fn, st));
-    if (heavy_idx.empty())
+    if (lh.n_next)
+        HIP_TRY(launch_sk_heavy_finals(lh.next, lh.n_next, kcount2, fn + (size_t)l1.n_next * 16, st));
+    if (nh == 0 || !heavy_expand)
         ps.free_now(rec1);
     *recs = rec0;
     *fin = fn;
-    *n_fin = l1.n_next * 16;
+    *n_fin = l1.n_next * 16 + lh.n_next;
     return DNAGPU_OK;
 }
 

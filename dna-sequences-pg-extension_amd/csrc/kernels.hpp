@@ -157,9 +157,11 @@ int sk_max_c0();          // most coarse buckets the level-0 sweeps support
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
                             u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s);
 hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
-                           hipStream_t s);
+                           hipStream_t s, bool by_d2 = false);
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
-                              const u32 *tot, hipStream_t s);
+                              const u32 *tot, hipStream_t s, bool by_d2 = false);
+// (by_d2: the same kernels on the 4-bit digit d2 -- the heavy mid buckets' split into final buckets)
+hipError_t launch_sk_heavy_finals(const Node *kids, u32 n, const u32 *kcount, Node *out, hipStream_t s);
 // buckets sk_count does not take, expanded to keys in record order (no host step): slices of sk_flat_slice() records
 // per bucket (n_slices[i], then after an exclusive scan slice_first[i]; slice_rec0 = first record, slice_nrec = records),
 // k-mers per slice, after a scan the keys of slice s at key_base + slice_koff[s] and one key node per bucket

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
 constexpr int SK1_NT = 1024;
 __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
                                                           u32 n_chunks, const ull2_t *__restrict__ recs,
-                                                          u32 *__restrict__ hist, u32 *__restrict__ kcount)
+                                                          u32 *__restrict__ hist, u32 *__restrict__ kcount, int shift)
 {
     __shared__ u32 h[ROW_STRIDE];
     __shared__ u32 kc[ROW_STRIDE];
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
     const u64 *hi = reinterpret_cast<const u64 *>(recs + (u64)nd.start + ch.off) + 1;
     for (u32 i = threadIdx.x; i < ch.len; i += SK1_NT) {
         const u64 m = __builtin_nontemporal_load(&hi[(u64)i * 2]);
-        const u32 d1 = (u32)(m >> 49) & (R - 1);
+        const u32 d1 = (u32)(m >> shift) & (R - 1);
         atomicAdd(&h[d1], 1u);
         atomicAdd(&kc[d1], (u32)((m >> 44) & 31) + 1u);
     }
@@ -420,7 +420,7 @@ constexpr int SK1_TILE = SK1_NT * SK1_ITEMS;
 __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
                                                              u32 n_chunks, const ull2_t *__restrict__ src_all,
                                                              ull2_t *__restrict__ dst_all, const u32 *__restrict__ hist,
-                                                             const u32 *__restrict__ tot)
+                                                             const u32 *__restrict__ tot, int shift)
 {
     __shared__ u32 cnt[ROW_STRIDE];
     __shared__ u32 gpos[ROW_STRIDE];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             rank[j] = 0;
             if (i < n_tile) {
                 const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
-                dig[j] = (u32)(m >> 49) & (R - 1);
+                dig[j] = (u32)(m >> shift) & (R - 1);
                 rank[j] = atomicAdd(&cnt[dig[j]], 1u);
             }
         }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             const u32 s = tid + j * SK1_NT;
             if (s < n_tile) {
                 const ull2_t r = src[t0 + idx[s]];
-                const u32 d = (u32)(r.y >> 49) & (R - 1);
+                const u32 d = (u32)(r.y >> shift) & (R - 1);
                 __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s - cnt[d])]);
             }
         }
@@ -1735,22 +1735,49 @@ hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, con
 }
 
 hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
-                           hipStream_t s)
+                           hipStream_t s, bool by_d2)
 {
     if (n_chunks == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_hist1_kernel, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
-                       reinterpret_cast<const ull2_t *>(recs), hist, kcount);
+                       reinterpret_cast<const ull2_t *>(recs), hist, kcount, by_d2 ? 59 : 49);
     return hipGetLastError();
 }
 
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
-                              const u32 *tot, hipStream_t s)
+                              const u32 *tot, hipStream_t s, bool by_d2)
 {
     if (n_chunks == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_scatter1_kernel, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
-                       reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), hist, tot);
+                       reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), hist, tot, by_d2 ? 59 : 49);
+    return hipGetLastError();
+}
+
+// the 16 children of the heavy mid buckets (split by d2 with the chunked level kernels) as final-bucket nodes: start / len
+// in records, child_base = k-mers; their quads are not counted (chunk_base = ~0: never sk_count's)
+__global__ __launch_bounds__(256) void sk_heavy_finals_kernel(const Node *__restrict__ kids, u32 n, const u32 *__restrict__ kcount,
+                                                              Node *__restrict__ out)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    Node o;
+    o.start = kids[i].start;
+    o.len = kids[i].len;
+    o.meta = 0;
+    o.split = 0;
+    o.prefix = 0;
+    o.child_base = kids[i].len ? kcount[i] : 0u;
+    o.chunk_base = ~0u;
+    out[i] = o;
+}
+
+hipError_t launch_sk_heavy_finals(const Node *kids, u32 n, const u32 *kcount, Node *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_heavy_finals_kernel, dim3((n + 255) / 256), dim3(256), 0, s, kids, n, kcount, out);
     return hipGetLastError();
 }
 

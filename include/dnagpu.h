@@ -338,6 +338,10 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
 /* DNAGPU_DEBUG_FORCE_SUPERKMER: dnagpu_count_kmers_unordered takes the super-k-mer engine for every k it supports
  * (23..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
 #define DNAGPU_DEBUG_FORCE_SUPERKMER 2u
+/* DNAGPU_DEBUG_HEAVY_EXPAND: the super-k-mer engine expands its heavy mid buckets to keys for the ordinary levels (the
+ * older path, still what records received from other ranks take when most of them are heavy) instead of splitting
+ * them with the chunked level kernels. */
+#define DNAGPU_DEBUG_HEAVY_EXPAND 4u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

@@ -689,13 +689,17 @@ def test_count_unordered_repeats(ctx, pkg, kind):
     h.free()
     # the engine forced: its "heavy bucket" limit is then 16 K k-mers, so the repeats' buckets leave the record path
     # through the eight-wave expansion (what buckets of millions of k-mers do at full size)
-    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
-    try:
-        h = ctx.count_kmers_unordered(d, k)
-        check_hist_unordered(h, ok, oc, f"unordered {kind}, heavy buckets split off")
-        h.free()
-    finally:
-        ctx.set_debug(0)
+    # (heavy mid buckets: split by d2 with the chunked level kernels, then sk_count_big -- and, with
+    # DEBUG_HEAVY_EXPAND, the older path: expanded to keys as a whole)
+    for flags, what in ((pkg.DEBUG_FORCE_SUPERKMER, "heavy buckets split by the level kernels"),
+                        (pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_HEAVY_EXPAND, "heavy buckets expanded")):
+        ctx.set_debug(flags)
+        try:
+            h = ctx.count_kmers_unordered(d, k)
+            check_hist_unordered(h, ok, oc, f"unordered {kind}, {what}")
+            h.free()
+        finally:
+            ctx.set_debug(0)
     # a short sequence (few, small buckets) of the same kind, the engine forced
     ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
     try:
@@ -813,6 +817,23 @@ def test_count_kmers_owned(ctx, n_owners):
         assert_same(np.concatenate(all_k), fk, "owners concatenated = global keys")
         assert_same(np.concatenate(all_c), fc, "owners concatenated = global counts")
         d.free()
+
+
+@pytest.mark.parametrize("motif", [1000, 64, 1, 100000])
+def test_count_unordered_repeats_at_size(ctx, motif):
+    """repeat-rich inputs at 600 Mbase with the engine's own thresholds (heavy mid buckets by k-mers or records, sliced big
+    buckets, merges): the unordered histogram's digest equals the ordered engine's"""
+    n, k = 600_000_000, 31
+    d = ctx.synth(0xD2A0007 + motif, n, motif_len=motif)
+    ht = ctx.count_kmers(d, k)
+    want = ht.summary()
+    ht.free()
+    hu = ctx.count_kmers_unordered(d, k)
+    assert hu.summary() == want
+    assert hu.total == n - k + 1
+    hu.free()
+    d.free()
+    ctx.trim()
 
 
 # ------------------------------------------------------------------ the unordered count in two halves (record exchange)
