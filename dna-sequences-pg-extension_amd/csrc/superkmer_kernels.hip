@@ -13,7 +13,9 @@
 //                            into C0 coarse buckets (1.8 B per k-mer instead of 8)
 //   sk_hist1 / sk_scatter1   records of a coarse bucket -> 2^b1 mid buckets
 //   sk_regroup               a mid bucket's records regrouped by d2: 16 final buckets of ~2,900 k-mers
-//   sk_count                 a final bucket counted from its records in an LDS hash table; groups appended to the output
+//   sk_count                 a final bucket counted from its records in an LDS hash table (fingerprint slots); its groups go
+//                            to its own output range
+//   sk_count_big / sk_big_merge   long final buckets of few distinct keys (repeats): one table per bucket, slices of records
 //   sk_slice_kmers / sk_expand_flat   the buckets sk_count does not take (oversize; the heavy buckets of repeats) -> keys;
 //                            the ordinary tree takes over at level 2 (skew handling included)
 //

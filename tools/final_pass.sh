@@ -10,6 +10,8 @@ python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 python3 bench.py --engine tree --no-cpu-baseline > $O/bench_tree.json 2>> $O/bench.err || exit 1
 python3 bench.py --motif 1000 --no-cpu-baseline > $O/bench_cfg4_motif1000.json 2>> $O/bench.err || exit 1
 python3 bench.py --motif 100000 --no-cpu-baseline > $O/bench_cfg4_motif100000.json 2>> $O/bench.err || exit 1
+python3 bench.py --motif 64 --no-cpu-baseline > $O/bench_cfg4_motif64.json 2>> $O/bench.err || exit 1
+python3 bench.py --motif 1 --no-cpu-baseline > $O/bench_cfg4_polyA_half.json 2>> $O/bench.err || exit 1
 python3 bench.py --config 2 > $O/bench_cfg2.json 2>> $O/bench.err || exit 1
 python3 bench.py --config 2 --motif 1000 --no-cpu-baseline > $O/bench_cfg2_motif1000.json 2>> $O/bench.err || exit 1
 python3 bench.py --config 3 > $O/bench_cfg3.json 2>> $O/bench.err || exit 1
