@@ -1186,6 +1186,8 @@ constexpr int SKB_REC = 512;                     // records per tile
 constexpr int SKB_MAXQ = SKB_REC * 8;            // quads of a tile (a record holds at most 32 k-mers)
 constexpr u32 SKB_ROUND_CAP = SKB_SLOTS - SKB_NT * SKC_KPT - 64;   // a round of inserts (<= 4096 new keys) starts below this
 constexpr u64 SKB_EMPTY = ~(u64)0;
+constexpr int SKB_RTAB_BITS = 10;
+static_assert((1 << SKB_RTAB_BITS) == SKB_NT, "one record-table slot per thread");
 
 // the table's groups, compacted: eight consecutive slots per thread, wave by wave; returns the number of groups (a count
 // of the all-ones key, which the table cannot hold, goes last).  All threads of the workgroup call it.
@@ -1270,7 +1272,8 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKB_REC];
     __shared__ unsigned short ownq[SKB_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wq[RWAVES], wtot[WAVES], wnew[2][WAVES];
-    __shared__ unsigned short mult[SKB_REC];       // copies a record stands for (0: the record equals its predecessor)
+    __shared__ u32 mult[SKB_REC];                  // records of the tile equal to this one (counted at the first to arrive)
+    __shared__ u32 rtab[SKB_NT];                   // the tile's distinct records: record indices, hashed by content
     __shared__ u32 ones;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 kmask = kmer_mask(k);
@@ -1281,6 +1284,14 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
         const u64 obase = list_off[lq];
         const Node nd = fin[li];
         const u32 r_lo = sj * SKB_SLICE_REC, r_hi = nd.len - r_lo < SKB_SLICE_REC ? nd.len : r_lo + SKB_SLICE_REC;
+        if (ns > 1) {
+            // the padding of a sliced bucket's output range (as long as its k-mers: hundreds of MB for a bucket of a long
+            // repeat) is written by all its slices, a share each, before the merge puts the groups at its start -- one
+            // workgroup zeroing 800 MB alone took 13 ms
+            const u64 z_lo = (u64)nd.child_base * sj / ns, z_hi = (u64)nd.child_base * (sj + 1) / ns;
+            for (u64 i = z_lo + (u64)tid; i < z_hi; i += SKB_NT)
+                out_counts[obase + i] = 0;
+        }
         for (int q = tid; q < SKB_SLOTS; q += SKB_NT) {
             tab[q] = SKB_EMPTY;
             cnt[q] = 0;
@@ -1292,9 +1303,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
         u32 distinct = 0, rpar = 0;                // (every thread keeps the same count: no shared counter to race on)
         for (u32 t0 = r_lo; t0 < r_hi && !failed; t0 += SKB_REC) {
             // ---- the tile's records into LDS.  A repeat brings the SAME record again and again (the same stretch of
-            // sequence cut at the same places), and the passes keep source order inside a bucket: a record equal to its
-            // predecessor in the tile is not expanded again -- the first of a run of equal records (runs are cut at wave
-            // boundaries) stands for all of them with a multiplicity.
+            // sequence cut at the same places): equal records of a tile are expanded once, with a multiplicity.
             u32 nq = 0, qinc = 0;
             ull2_t myr;
             myr.x = myr.y = 0;
@@ -1305,19 +1314,31 @@ __global__ __launch_bounds__(SKB_NT) void sk_count_big_kernel(const Node *__rest
                     mylen = (u32)((myr.y >> 44) & 31) + 1u;
                 }
                 lrec[tid] = myr;
+                mult[tid] = 1u;
             }
+            rtab[tid] = SKC_FREE;                  // (SKB_RTAB == SKB_NT slots)
             __syncthreads();
-            if (tid < SKB_REC) {
-                bool head = mylen != 0;
-                if (head && lane != 0) {
-                    const ull2_t prev = lrec[tid - 1];
-                    head = prev.x != myr.x || prev.y != myr.y;
+            // equal records of the tile, wherever they stand (the copies of a repeat's records alternate when several of them
+            // share a bucket): a small table of record INDICES; a record that finds an equal one ahead of it adds to
+            // that one's multiplicity and is not expanded
+            bool head = false;
+            if (tid < SKB_REC && mylen != 0) {
+                u32 hslot = (((u32)myr.x ^ (u32)(myr.x >> 32) ^ (u32)myr.y) * 0x9E3779B1u) >> (32 - SKB_RTAB_BITS);
+                for (;;) {
+                    const u32 old = atomicCAS(&rtab[hslot], SKC_FREE, (u32)tid);
+                    if (old == SKC_FREE) {
+                        head = true;
+                        break;
+                    }
+                    const ull2_t other = lrec[old];
+                    if (other.x == myr.x && other.y == myr.y) {
+                        atomicAdd(&mult[old], 1u);
+                        break;
+                    }
+                    hslot = (hslot + 1) & (u32)(SKB_NT - 1);
                 }
-                const u64 hm = __ballot(head), vm = __ballot(mylen != 0);
-                // the run of a head: up to the next head, or to the end of the wave's records
-                const u64 later = lane == 63 ? 0 : hm & ~(((u64)2 << lane) - 1);
-                const u32 nxt = later ? (u32)__builtin_ctzll(later) : (u32)__popcll(vm);   // (records of a tile are a prefix of the lanes)
-                mult[tid] = head ? (nxt > (u32)lane ? nxt - (u32)lane : 1u) : 0u;
+            }
+            if (tid < SKB_REC) {
                 nq = head ? (mylen + SKC_KPT - 1) / SKC_KPT : 0u;
                 qinc = wave_incl_scan(nq);
                 if (lane == 63)
@@ -1498,9 +1519,7 @@ __global__ __launch_bounds__(SKB_NT) void sk_big_merge_kernel(const Node *__rest
     }
     __syncthreads();
     if (!failed) {
-        const u32 groups = skb_emit(tab, cnt, ones, wtot, out_keys + obase, out_counts + obase);
-        for (u32 i = groups + (u32)tid; i < nd.child_base; i += SKB_NT)
-            out_counts[obase + i] = 0;
+        const u32 groups = skb_emit(tab, cnt, ones, wtot, out_keys + obase, out_counts + obase);   // (the rest of the range: zeroed by the slices)
         if (tid == 0) {
             seg_off[li] = obase;
             seg_cnt[li] = groups;
@@ -1508,8 +1527,6 @@ __global__ __launch_bounds__(SKB_NT) void sk_big_merge_kernel(const Node *__rest
             atomicAdd(n_groups, (unsigned long long)groups);
         }
     } else {
-        for (u32 i = tid; i < nd.child_base; i += SKB_NT)
-            out_counts[obase + i] = 0;
         if (tid == 0) {
             seg_off[li] = obase;
             seg_cnt[li] = 0;
