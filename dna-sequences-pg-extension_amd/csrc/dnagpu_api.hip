@@ -1243,8 +1243,8 @@ constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final buc
 // expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
 // few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
 constexpr u64 SK_MID_LIMIT = (u64)1 << 27;
-constexpr u32 SK_MID_RECORDS = 1u << 21;           // (a mid bucket is regrouped by one workgroup: ~250 tiles, twice)
-constexpr u64 SK_BIG_LIMIT = (u64)1 << 30;
+constexpr u32 SK_MID_RECORDS = 1u << 19;           // (a mid bucket is regrouped by one workgroup: 64 tiles, twice)
+constexpr u64 SK_BIG_LIMIT = 0xFFFFFFFFull;
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;
