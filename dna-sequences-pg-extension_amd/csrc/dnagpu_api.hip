@@ -1601,15 +1601,20 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     RC_TRY(ps.alloc(8, &totals));
     RC_TRY(ps.alloc((size_t)n_fin, &list_small));
     RC_TRY(ps.alloc((size_t)n_fin, &off_small));
-    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, big_limit, f_small, f_big, k_range, st));
+    RC_TRY(ps.alloc((size_t)n_fin, &f_over));       // (first: the k-mers of the big buckets, summed)
+    HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, big_limit, f_small, f_big, k_range, f_over, st));
     HIP_TRY(launch_scan_u32(f_small, f_small, n_fin, scan_tmp, totals + 0, st));
     HIP_TRY(launch_scan_u32(f_big, f_big, n_fin, scan_tmp, totals + 1, st));
     HIP_TRY(launch_scan_u32(k_range, k_range, n_fin, scan_tmp, totals + 2, st));
-    u32 ht[3] = {0, 0, 0};
+    HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 3, st));
+    u32 ht[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ht, totals, sizeof ht, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const u32 n_small = ht[0], n_big = ht[1];
     const u64 small_keys = ht[2];                // the output slots of the small and big buckets: one per k-mer, in bucket order
+    // a big bucket that sk_count_big gives up on is counted again through the expansion: its groups land behind the
+    // ranges while its own range stays padding, so the arrays hold up to n + the big buckets' k-mers
+    const u64 out_cap = n + ht[3];
     RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &list_big));
     RC_TRY(ps.alloc((size_t)std::max<u32>(n_big, 1), &off_big));
     HIP_TRY(launch_sk_select_lists(fin, n_fin, cap, big_limit, f_small, f_big, k_range, list_small, off_small, list_big, off_big, st));
@@ -1620,8 +1625,8 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     // [0] next free output slot of the leaves behind the buckets' ranges; [1] buckets whose expansion disagrees with the
     // partition's count; [2] groups sk_count and sk_count_big wrote
     RC_TRY(ps.alloc(3, &cursor));
-    RC_TRY(ps.alloc((size_t)n, &ok));
-    RC_TRY(ps.alloc((size_t)n, &oc));
+    RC_TRY(ps.alloc((size_t)out_cap, &ok));
+    RC_TRY(ps.alloc((size_t)out_cap, &oc));
     {
         const u64 init[3] = {small_keys, 0, 0};
         HIP_TRY(hipMemcpyAsync(cursor, init, sizeof init, hipMemcpyHostToDevice, st));
@@ -1664,7 +1669,6 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
                                     seg_off_fin, seg_cnt_fin, ok, oc, big_status, part_keys, part_cnts, part_n, n_part > 0, st));
     }
     prof_mark(ctx, "sk_select_over");
-    RC_TRY(ps.alloc((size_t)n_fin, &f_over));
     RC_TRY(ps.alloc((size_t)n_fin, &f_over_raw));
     RC_TRY(ps.alloc((size_t)n_fin, &k_over));
     HIP_TRY(launch_sk_over_flags(fin, n_fin, cap, big_limit, f_big, big_status, f_over_raw, k_over, st));
@@ -1752,6 +1756,10 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     if (fin_ctr[1] != 0) {
         set_err("super-k-mer count: %llu buckets whose records expand to a different number of k-mers than the partition counted",
                 (unsigned long long)fin_ctr[1]);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    if (extent > out_cap) {
+        set_err("super-k-mer count: %llu output slots used, %llu allocated", (unsigned long long)extent, (unsigned long long)out_cap);
         return DNAGPU_ERR_INTERNAL;
     }
     if (total_groups > n) {

@@ -188,7 +188,7 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off
 
 int sk_count_cap();       // most k-mers a final bucket may hold to be counted from its records
 hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, u32 *f_small, u32 *f_big, u32 *k_range,
-                                  hipStream_t s);
+                                  u32 *k_big, hipStream_t s);
 hipError_t launch_sk_select_lists(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, const u32 *p_small, const u32 *p_big,
                                   const u32 *kb_range, u32 *list_small, u32 *off_small, u32 *list_big, u32 *off_big, hipStream_t s);
 // buckets that go through the expansion: too many k-mers for sk_count_big, or given up by it (big_status[p] != 0)

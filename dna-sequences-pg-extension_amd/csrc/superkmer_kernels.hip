@@ -1610,7 +1610,7 @@ __device__ __forceinline__ u32 sk_bucket_class(const Node &nd, u32 cap, u32 big_
 // flags (to be scanned in place) and the k-mers that take output slots (small and big buckets: k_range) / key slots (over)
 __global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap, u32 big_limit,
                                                               u32 *__restrict__ f_small, u32 *__restrict__ f_big,
-                                                              u32 *__restrict__ k_range)
+                                                              u32 *__restrict__ k_range, u32 *__restrict__ k_big)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_fin)
@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(256) void sk_select_flags_kernel(const Node *__rest
     f_small[i] = c == 1u ? 1u : 0u;
     f_big[i] = c == 2u ? 1u : 0u;
     k_range[i] = c == 1u || c == 2u ? fin[i].child_base : 0u;
+    k_big[i] = c == 2u ? fin[i].child_base : 0u;
 }
 
 __global__ __launch_bounds__(256) void sk_select_lists_kernel(const Node *__restrict__ fin, u32 n_fin, u32 cap, u32 big_limit,
@@ -1666,12 +1667,12 @@ __global__ __launch_bounds__(256) void sk_over_list_kernel(const Node *__restric
 }
 
 hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, u32 *f_small, u32 *f_big, u32 *k_range,
-                                  hipStream_t s)
+                                  u32 *k_big, hipStream_t s)
 {
     if (n_fin == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_select_flags_kernel, dim3((n_fin + 255) / 256), dim3(256), 0, s, fin, n_fin, cap, big_limit, f_small, f_big,
-                       k_range);
+                       k_range, k_big);
     return hipGetLastError();
 }
 

@@ -929,6 +929,46 @@ def test_count_records_fingerprint_collisions(ctx, pkg):
     ctx.buffer_free(buf)
 
 
+@pytest.mark.parametrize("kind", ["many-distinct", "sliced-few", "sliced-overflow", "sliced-polyG"])
+def test_count_records_big_buckets(ctx, pkg, kind):
+    """sk_count_big on hand-made buckets (records of one k-mer each, one final bucket): more distinct keys than its table
+    holds (the bucket must come back through the expansion), a bucket of several slices with few distinct keys (partial
+    areas + merge), a sliced bucket that overflows in the merge, and the all-ones key (k = 32 poly-G), which the table
+    cannot hold as a key."""
+    k = 32 if kind == "sliced-polyG" else 31
+    rows = 50_000_000
+    nb = ctx.sk_buckets(rows, k)
+    rng = np.random.default_rng(11)
+    kmask = (1 << (2 * k)) - 1
+    if kind == "many-distinct":
+        keys = rng.integers(0, 1 << 62, 9000, dtype=np.uint64) & np.uint64(kmask)
+    elif kind == "sliced-few":
+        pool = rng.integers(0, 1 << 62, 37, dtype=np.uint64) & np.uint64(kmask)
+        keys = pool[rng.integers(0, len(pool), 150_000)]
+    elif kind == "sliced-overflow":
+        pool = rng.integers(0, 1 << 62, 7000, dtype=np.uint64) & np.uint64(kmask)
+        keys = pool[rng.integers(0, len(pool), 150_000)]
+    else:
+        pool = np.concatenate([np.array([kmask], dtype=np.uint64), rng.integers(0, 1 << 63, 20, dtype=np.uint64) & np.uint64(kmask)])
+        keys = pool[rng.integers(0, len(pool), 140_000)]
+    d1, d2, bucket = 9, 1, 0
+    recs = np.empty(2 * len(keys), dtype=np.uint64)
+    if k == 31:
+        recs[0::2] = keys
+        recs[1::2] = np.uint64((d1 << 49) | (d2 << 59))
+    else:                                          # 32 bases: all of lo; hi carries no base
+        recs[0::2] = keys
+        recs[1::2] = np.uint64((d1 << 49) | (d2 << 59))
+    buf = ctx.buffer_alloc(recs.nbytes)
+    ctx.upload_u64(buf, recs)
+    h = ctx.count_records([(buf, len(keys), bucket)], k, rows)
+    ok, oc = np.unique(keys, return_counts=True)
+    assert h.total == len(keys)
+    check_hist_unordered(h, ok, oc.astype(np.uint64), f"crafted big bucket: {kind}")
+    h.free()
+    ctx.buffer_free(buf)
+
+
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
