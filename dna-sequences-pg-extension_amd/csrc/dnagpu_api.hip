@@ -2830,8 +2830,34 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
     // ---- every owner: its buckets' pieces from all ranks
     if (rc == DNAGPU_OK) {
         const u32 nb = dnagpu_records_buckets(recs[0]);
+        // owners: contiguous bucket ranges balanced by the records the buckets hold on all ranks (shard_math.py:
+        // bucket_owner_ranges_weighted -- a bucket goes to the side its middle falls on)
+        std::vector<u64> wgt(nb, 0);
+        u64 wtotal = 0;
+        for (int r = 0; r < W; r++)
+            for (u32 b = 0; b < nb; b++) {
+                wgt[b] += recs[(size_t)r]->off[b + 1] - recs[(size_t)r]->off[b];
+                wtotal += recs[(size_t)r]->off[b + 1] - recs[(size_t)r]->off[b];
+            }
+        std::vector<u32> cut((size_t)W + 1, 0);
+        cut[(size_t)W] = nb;
+        if (wtotal == 0) {
+            for (int o = 1; o < W; o++)
+                cut[(size_t)o] = (u32)(((u64)o * nb + (u64)W - 1) / (u64)W);
+        } else {
+            u64 run = 0;
+            u32 b = 0;
+            for (int o = 1; o < W; o++) {
+                const double target = (double)wtotal * o / W;
+                while (b < nb && (double)run + (double)wgt[b] / 2 <= target) {
+                    run += wgt[b];
+                    b++;
+                }
+                cut[(size_t)o] = b;
+            }
+        }
         run_all([&](int o) {
-            const u32 b_lo = (u32)(((u64)o * nb + (u64)W - 1) / (u64)W), b_hi = (u32)(((u64)(o + 1) * nb + (u64)W - 1) / (u64)W);
+            const u32 b_lo = cut[(size_t)o], b_hi = std::max(cut[(size_t)o + 1], cut[(size_t)o]);
             std::vector<const void *> ptr;
             std::vector<u64> len;
             std::vector<u32> bk;

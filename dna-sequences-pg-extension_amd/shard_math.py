@@ -54,3 +54,22 @@ def bucket_owner_ranges(n_buckets, world):
         hi = ((o + 1) * n_buckets + world - 1) // world
         out.append((lo, max(hi, lo)))
     return out
+
+
+def bucket_owner_ranges_weighted(weights, world):
+    """The same contiguous split, balanced by weight (records per bucket, summed over all ranks): owner o's range ends at
+    the bucket where the running total comes closest to (o + 1) / world of the whole.  Every rank computes it from the
+    same all-gathered counts.  Falls back to the even split when there is nothing to weigh."""
+    nb = len(weights)
+    total = sum(int(w) for w in weights)
+    if total == 0 or world == 1:
+        return bucket_owner_ranges(nb, world)
+    cuts, run, b = [0], 0, 0
+    for o in range(1, world):
+        target = total * o / world
+        while b < nb and run + int(weights[b]) / 2 <= target:      # (the bucket goes to the side its middle falls on)
+            run += int(weights[b])
+            b += 1
+        cuts.append(b)
+    cuts.append(nb)
+    return [(cuts[o], max(cuts[o + 1], cuts[o])) for o in range(world)]

@@ -26,7 +26,8 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from .shard_math import OWNER_BITS, bucket_owner_ranges, owner_key_range, shard_ranges, word_chunks  # noqa: F401  (pure arithmetic: no torch)
+from .shard_math import (OWNER_BITS, bucket_owner_ranges, bucket_owner_ranges_weighted, owner_key_range,  # noqa: F401
+                         shard_ranges, word_chunks)  # (pure arithmetic: no torch)
 
 
 class _DevArray:
@@ -196,7 +197,6 @@ def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=No
     if dna is None:
         dna = engine.make_shard(seed, base_lo, base_hi)
     n_buckets = engine.sk_buckets(global_rows, k)
-    owners = bucket_owner_ranges(n_buckets, world)
     send, boffs = engine.sk_records(dna, k, n_mine, global_rows)        # records grouped by bucket = by owner
     # what every rank holds of every bucket: the receiver needs the piece boundaries inside what it is sent
     via_host = dist.get_backend() == "gloo"
@@ -208,6 +208,8 @@ def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=No
     else:
         dist.all_gather_into_tensor(all_counts, counts)
     all_counts = all_counts.cpu().view(world, n_buckets)
+    # owners: contiguous bucket ranges, balanced by the records the buckets hold (the same split on every rank)
+    owners = bucket_owner_ranges_weighted([int(x) for x in all_counts.sum(dim=0).tolist()], world)
     lo, hi = owners[rank]
     # split sizes in int64 words (two per record); what arrives is known from the counts: no size exchange
     in_splits = [2 * (boffs[min(owners[o][1], n_buckets)] - boffs[min(owners[o][0], n_buckets)]) for o in range(world)]

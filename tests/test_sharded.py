@@ -81,6 +81,25 @@ def test_bucket_owner_ranges_cover_exactly_once():
             assert r[o][0] <= b < r[o][1]
 
 
+def test_bucket_owner_ranges_weighted():
+    pkg = load_package()
+    sh = importlib.import_module(pkg.__name__ + ".shard_math")
+    import random
+    rnd = random.Random(5)
+    for nb, w in [(68, 8), (64, 8), (7, 3), (1, 4), (128, 6), (3, 8), (68, 1)]:
+        for trial in range(20):
+            weights = [rnd.randint(0, 1000) if rnd.random() < 0.9 else 0 for _ in range(nb)]
+            r = sh.bucket_owner_ranges_weighted(weights, w)
+            assert len(r) == w and r[0][0] == 0 and r[-1][1] == nb
+            for (lo, hi), (lo2, _) in zip(r, r[1:]):
+                assert lo <= hi == lo2
+            tot = sum(weights)
+            if tot and w > 1 and nb >= 4 * w:
+                share = [sum(weights[lo:hi]) for lo, hi in r]
+                assert max(share) <= tot / w + max(weights), (nb, w, share)     # within one bucket of the even share
+    assert sh.bucket_owner_ranges_weighted([0] * 10, 3) == sh.bucket_owner_ranges(10, 3)
+
+
 @pytest.mark.parametrize("world,n_bases,k", [(2, 200_000, 31), (3, 100_001, 25), (2, 5000, 23)])
 def test_sharded_records_gloo_oracle_engine(tmp_path, world, n_bases, k):
     """the record exchange's host logic (bucket owners, split sizes, piece boundaries) with the oracle standing in"""
