@@ -22,7 +22,6 @@ with pkg.Context(0) as ctx:
     nb = ctx.sk_buckets(rows, k)
     for W in worlds:
         shards = sh.shard_ranges(n, k, W)
-        owners = sh.bucket_owner_ranges(nb, W)
         recs, t_l0 = [], []
         for first, cnt, lo, hi in shards:
             d = ctx.synth(seed + lo // 32, hi - lo)
@@ -39,6 +38,7 @@ with pkg.Context(0) as ctx:
             t_l0.append(best)
             recs.append(r)
             d.free()
+        owners = sh.bucket_owner_ranges_weighted([sum(int(r.offsets[b + 1] - r.offsets[b]) for r in recs) for b in range(nb)], W)
         t_cnt, sent, recv, distinct = [], [], [], 0
         for o, (lo_b, hi_b) in enumerate(owners):
             pieces = [(r.device_ptr + 16 * int(r.offsets[b]), int(r.offsets[b + 1] - r.offsets[b]), b)
