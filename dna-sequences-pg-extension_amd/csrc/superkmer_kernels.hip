@@ -1464,7 +1464,6 @@ __global__ __launch_bounds__(SKB_NT) void sk_big_merge_kernel(const Node *__rest
         return;
     const u32 li = list[lq];
     const u64 obase = list_off[lq];
-    const Node nd = fin[li];
     for (int q = tid; q < SKB_SLOTS; q += SKB_NT) {
         tab[q] = SKB_EMPTY;
         cnt[q] = 0;
