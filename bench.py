@@ -188,7 +188,7 @@ def main():
                 # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
                 h, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
             distinct[0] = h.distinct
-            for name, ms in ctx.last_phase_times():
+            for name, ms in (engine.phase_times() if use_records else ctx.last_phase_times()):
                 phases_acc.setdefault(name, []).append(ms)
             h.free()
 

@@ -2027,6 +2027,7 @@ extern "C" int dnagpu_sk_records(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, 
         std::vector<Node> kids;
         prof_begin(ctx);
         const int rc = sk_level0(ctx, ps, dna, first, count, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs);
+        prof_mark(ctx, "end");
         prof_end(ctx);
         if (rc != DNAGPU_OK) {
             delete r;

@@ -108,9 +108,14 @@ class GpuEngine:
         """-> (int64 tensor view of the records, two words each, grouped by bucket; offsets per bucket in records)"""
         r = self.ctx.sk_records(dna, k, 0, count, global_rows)
         self._records = r
+        self._phases0 = list(self.ctx.last_phase_times())      # (level 0; the count's phases follow in count_records)
         if r.n_records == 0:
             return self.empty(0), [0] * (r.n_buckets + 1)
         return torch.as_tensor(_DevArray(r.device_ptr, 2 * r.n_records), device=self.device), [int(x) for x in r.offsets]
+
+    def phase_times(self):
+        """phase times of the last sharded count: the record cut (if any) followed by the count"""
+        return list(getattr(self, "_phases0", [])) + list(self.ctx.last_phase_times())
 
     def count_records(self, recv_t, pieces, k, global_rows):
         """pieces: [(offset in records inside recv_t, n_records, bucket)]"""
