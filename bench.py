@@ -6,9 +6,21 @@
   python bench.py --config {2,3,4,5} [--motif M] [--pattern P]   the other BASELINE.json configs / repeat-rich variants
 
 A step = one full GROUP BY count over the whole synthetic sequence (extraction fused in), input
-already resident in HBM.  N=1: the single-GPU path (dnagpu_count_kmers) on all 3 Gbase.  N>1:
-the same 3 Gbase sharded by contiguous chunk over the ranks (strong scaling), one RCCL all-gather
-of the packed sequence, then every rank counts the key range it owns (sharded.py).  Rank 0 prints ONE JSON line.
+already resident in HBM.  N=1: the single-GPU path (dnagpu_count_kmers_unordered) on all 3 Gbase.  N>1: the same
+3 Gbase sharded by contiguous chunk over the ranks (strong scaling), three ways to start it:
+
+  python bench.py --gpus N                       ONE process drives N GPUs through the C-ABI (dnagpu_multi_init +
+                                                 dnagpu_count_multi_unordered: every rank cuts the super-k-mer records of
+                                                 its own rows, owners pull their buckets' pieces over xGMI and count them
+                                                 while later pieces are in flight).  No torch.  This is the call a
+                                                 PostgreSQL backend makes (one backend process, nothing PARALLEL SAFE:
+                                                 dna--1.0.sql:188-195).  On a box with fewer than N devices the ranks
+                                                 share devices and the line says "rehearsal": true.
+  python bench.py --gpus N --launcher torchrun   spawns torch.distributed.run (one process per GPU, RCCL) as a CHILD
+                                                 before this process imports torch or touches a GPU, relays its line/rc
+  python -m torch.distributed.run ... bench.py --gpus N     (WORLD_SIZE in the environment) one process per GPU: the
+                                                 records travel in one RCCL all-to-all (sharded.py)
+Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
   roofline      the dominant kernel of the step: algorithmic bytes / its device time (HIP events on
@@ -90,7 +102,18 @@ def main():
                          "unspecified; super-k-mer partitioning for k >= 23 on long sequences), tree = "
                          "dnagpu_count_kmers (groups in ascending key order, MSD radix tree)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launcher", choices=["one-process", "torchrun"], default="one-process",
+                    help="--gpus N > 1 without WORLD_SIZE in the environment: one-process = this process drives all N GPUs "
+                         "through the C-ABI (default); torchrun = spawn torch.distributed.run as a child, one process per GPU")
+    ap.add_argument("--parts", type=int, default=0,
+                    help="one-process path: bucket groups per owner of the pipelined record exchange (0 = library default)")
+    ap.add_argument("--emulate-link-gbs", type=float, default=0.0,
+                    help="one-process REHEARSAL on shared devices: hold inbound pieces to this many GB/s per owner")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if args.launcher == "torchrun":
+            raise SystemExit(spawn_torchrun(args.gpus))
+        return main_one_process(args)
 
     cfg = dict(CONFIGS[args.config])
     if args.n_bases is not None:
@@ -278,9 +301,7 @@ def main():
                             "alg_bytes_per_launch": int(alg_bytes), "kernel_ms": round(means[dom], 3),
                             # PMC traffic is collected for the default single-GPU workload only
                             "traffic": load_traffic(dom) if (world == 1 and default_workload) else None}
-            job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS / world, 5),
-                   "alg_fraction": round((b_in + 16 * distinct[0]) / t_step / 1e9 / HBM_PEAK_GBS / world, 4),
-                   "alg_bytes_per_kmer": round((b_in + 16 * distinct[0]) / n_kmers, 3)}
+            job = job_fractions(b_in, distinct[0], n_kmers, t_step, world)
             metric = HEADLINE_METRIC if args.config == 4 else \
                 f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline"
             eng = "" if world > 1 else (", ordered groups (MSD radix tree)" if sorted_result[0] else ", unordered groups (super-k-mer partitioning)")
@@ -309,6 +330,165 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def spawn_torchrun(n_gpus):
+    """--launcher torchrun: the process-per-GPU path as a CHILD (this process has not imported torch nor touched a GPU,
+    and never execs: it relays the child's output and exit code)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    # drop "--launcher torchrun" from the child's arguments (WORLD_SIZE in its environment selects the path there)
+    out = []
+    skip = False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--launcher":
+            skip = True
+            continue
+        if a.startswith("--launcher="):
+            continue
+        out.append(a)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + out
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main_one_process(args):
+    """python bench.py --gpus N: N ranks driven from THIS process through the C-ABI (dnagpu_multi_*), no torch.
+    The same JSON contract; `phases_ms` = rank 0's device phases, `exchange` = the host clock of the call's phases."""
+    cfg = dict(CONFIGS[args.config])
+    if args.n_bases is not None:
+        cfg["n_bases"] = int(args.n_bases)
+    if args.k is not None:
+        cfg["k"] = args.k
+    if cfg["kind"] == "filter":
+        raise SystemExit("config 5 is a single-GPU workload (BASELINE.json)")
+    if args.motif:
+        raise SystemExit("--motif is a single-GPU option")
+    n_bases, k, seed = cfg["n_bases"], cfg["k"], cfg["seed"]
+    n_kmers = n_bases - k + 1
+    W = args.gpus
+    global SK_RUN
+    SK_RUN = (max(k - 14, 1) + 1) / 2.0
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    n_dev = pkg.device_count()
+    if n_dev < 1:
+        raise SystemExit("no HIP device")
+    rehearsal = n_dev < W
+    devices = [r % n_dev for r in range(W)]
+    # RCCL (all-gather / reduce of the ordered paths) when the devices are distinct and the library loads, else peer
+    # copies; the record exchange itself always pulls with peer copies
+    multi = pkg.Multi(devices, pkg.MULTI_AUTO)
+    if args.parts:
+        multi.set_parts(args.parts)
+    if args.emulate_link_gbs:
+        multi.emulate_link(args.emulate_link_gbs)
+    for c in multi.ranks:
+        c.set_profiling(True)
+    mdna = multi.synth(seed, n_bases)
+    use_records = args.engine != "tree" and k >= 23
+    count_fn = multi.count_unordered if use_records else multi.count
+
+    def sync_all():
+        for c in multi.ranks:
+            c.synchronize()
+
+    phases_acc, xacc = {}, {}
+    distinct = [0]
+
+    def step():
+        hs = count_fn(mdna, k)
+        distinct[0] = sum(h.distinct for h in hs)
+        for name, ms in multi.ranks[0].last_phase_times():
+            phases_acc.setdefault(name, []).append(ms)
+        if use_records:
+            for name, v in multi.last_times().items():
+                xacc.setdefault(name, []).append(v)
+        for h in hs:
+            h.free()
+
+    for _ in range(args.warmup):
+        step()
+    phases_acc.clear()
+    xacc.clear()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    ms_per_step = elapsed / args.steps * 1e3
+    t_step = elapsed / args.steps
+    value = n_kmers * args.steps / elapsed
+    means = {name: sum(v) / len(v) for name, v in phases_acc.items()}
+    b_in = 8 * ((n_bases + 31) // 32)
+    kern = {n_: m for n_, m in means.items() if phase_kind(n_)}
+    dom = max(kern, key=kern.get) if kern else None
+    roofline = None
+    if dom:
+        alg_bytes = PHASE_BYTES[phase_kind(dom)](n_kmers / W, distinct[0] / W, n_kmers)
+        achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": int(alg_bytes),
+                    "kernel_ms": round(means[dom], 3), "traffic": None,
+                    "note": "rank 0's share of the work (1/N of the rows); PMC traffic is collected for the single-GPU workload only"}
+    xm = {name: sum(v) / len(v) for name, v in xacc.items()}
+    exchange = None
+    if use_records:
+        exchange = {"what": "records: own rows -> super-k-mer records -> owners pull their coarse buckets (peer copies of "
+                            "16-byte records) -> counted group by group while later groups are in flight",
+                    "parts": int(xm.get("parts", 0)), "records_ms": round(xm.get("records_ms", 0), 3),
+                    "exchange_ms": round(xm.get("exchange_ms", 0), 3), "hidden_ms": round(xm.get("hidden_ms", 0), 3),
+                    "owners_ms": round(xm.get("count_ms", 0), 3), "call_ms": round(xm.get("total_ms", 0), 3),
+                    "MB_moved_per_step": round(xm.get("bytes_moved", 0) / 1e6, 1),
+                    **({"emulated_link_GBs_per_owner": args.emulate_link_gbs} if args.emulate_link_gbs else {})}
+    else:
+        exchange = {"what": "sequence: all-gather of the packed chunks -> every rank counts the key range it owns"}
+    line = {
+        "metric": HEADLINE_METRIC if args.config == 4 else
+        f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline",
+        "value": value, "unit": "k-mers/s", "n_gpus": W, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}), "
+                               f"sharded by contiguous chunk over {W} ranks driven by one process through the C-ABI "
+                               f"(dnagpu_count_multi{'_unordered' if use_records else ''})",
+                   "n_bases": n_bases, "k": k, "distinct": distinct[0]},
+        "launcher": "one-process", "devices": devices, "transport": multi.transport, "rehearsal": rehearsal,
+        "roofline": roofline,
+        "job_roofline": job_fractions(b_in, distinct[0], n_kmers, t_step, W),
+        "phases_ms": {n_: round(m, 4) for n_, m in means.items()},
+        "exchange": exchange,
+    }
+    if rehearsal:
+        line["rehearsal_note"] = (f"{W} ranks share {n_dev} device(s): the code path of the N-GPU run (chunk residency, halo "
+                                  "word, per-rank records, owners' pulls, pipelined count), NOT a scaling measurement")
+    print(json.dumps(line), flush=True)
+    multi.dna_free(mdna)
+    multi.close()
+
+
+def job_fractions(b_in, distinct, n_kmers, t_step, world):
+    """SURVEY.md 8(d)'s whole-job fractions.  alg_fraction prices a group at SURVEY's 16 B (8-byte key + 8-byte count);
+    the kernels write 12 B (uint32 counts, widened on download): both are reported."""
+    per_gpu = t_step * 1e9 * HBM_PEAK_GBS * world
+    return {"read_fraction": round(b_in / per_gpu, 5),
+            "alg_fraction_16B": round((b_in + 16 * distinct) / per_gpu, 4),
+            "alg_fraction_12B": round((b_in + 12 * distinct) / per_gpu, 4),
+            "alg_fraction": round((b_in + 16 * distinct) / per_gpu, 4),
+            "alg_bytes_per_kmer": round((b_in + 16 * distinct) / n_kmers, 3),
+            "alg_bytes_per_kmer_written": round((b_in + 12 * distinct) / n_kmers, 3)}
 
 
 def load_traffic(kernel):

@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     MULTI_RCCL,
     Multi,
     abi_version,
+    device_count,
     kmer_count,
     lib,
     lib_path,

@@ -42,6 +42,11 @@ class _PhaseTimes(C.Structure):
     _fields_ = [("n", C.c_int), ("names", C.c_char_p * MAX_PHASES), ("ms", C.c_float * MAX_PHASES)]
 
 
+class _MultiTimes(C.Structure):
+    _fields_ = [("records_ms", C.c_double), ("exchange_ms", C.c_double), ("hidden_ms", C.c_double),
+                ("count_ms", C.c_double), ("total_ms", C.c_double), ("bytes_moved", C.c_uint64), ("parts", C.c_int)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libdnagpu.so")
 
@@ -146,6 +151,13 @@ def lib():
     L.dnagpu_multi_dna_free.restype = None
     L.dnagpu_count_multi.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_count_multi_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.dnagpu_device_count.restype = C.c_int
+    L.dnagpu_multi_set_option.argtypes = [vp, C.c_int, C.c_double]
+    L.dnagpu_multi_last_times.argtypes = [vp, C.POINTER(_MultiTimes)]
+    L.dnagpu_hist_parts.argtypes = [vp]
+    L.dnagpu_hist_parts.restype = C.c_uint32
+    L.dnagpu_hist_part.argtypes = [vp, C.c_uint32]
+    L.dnagpu_hist_part.restype = vp
     L.dnagpu_last_phase_times.argtypes = [vp, C.POINTER(_PhaseTimes)]
     L.dnagpu_set_profiling.argtypes = [vp, C.c_int]
     L.dnagpu_set_debug.argtypes = [vp, C.c_uint]
@@ -168,6 +180,11 @@ def _chk(rc):
 
 def strerror(code):
     return lib().dnagpu_strerror(code).decode()
+
+
+def device_count():
+    """HIP devices this process can use (no context is created)"""
+    return int(lib().dnagpu_device_count())
 
 
 def abi_version():
@@ -268,6 +285,16 @@ class Hist:
     @property
     def device_counts(self):
         return lib().dnagpu_hist_device_counts(self.h)
+
+    @property
+    def n_parts(self):
+        """device-array sets this histogram consists of (the pipelined multi-GPU count makes several)"""
+        return int(lib().dnagpu_hist_parts(self.h))
+
+    def part_arrays(self, i):
+        """(device keys pointer, device counts pointer, extent) of part i"""
+        ph = C.c_void_p(lib().dnagpu_hist_part(self.h, i))
+        return (lib().dnagpu_hist_device_keys(ph), lib().dnagpu_hist_device_counts(ph), int(lib().dnagpu_hist_extent(ph)))
 
     @property
     def is_sorted(self):
@@ -541,6 +568,7 @@ class Context:
 
 
 MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
+MULTI_OPT_PARTS, MULTI_OPT_EMULATE_LINK_GBS = 1, 2
 
 
 class _BorrowedContext(Context):
@@ -548,6 +576,11 @@ class _BorrowedContext(Context):
 
     def __init__(self, handle):
         self.h = C.c_void_p(handle)
+        # the same test-harness switch as Context: the rank contexts of a Multi are created in C, so the poison flag
+        # is set on them here
+        self._base_debug = DEBUG_POISON_POOL if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0") else 0
+        if self._base_debug:
+            self.set_debug(0)
 
     def close(self):
         self.h = None
@@ -567,6 +600,19 @@ class Multi:
     @property
     def transport(self):
         return lib().dnagpu_multi_transport(self.h).decode()
+
+    def set_parts(self, parts):
+        """bucket groups per owner of count_unordered's pipelined exchange (1 = no overlap)"""
+        _chk(lib().dnagpu_multi_set_option(self.h, MULTI_OPT_PARTS, float(parts)))
+
+    def emulate_link(self, gb_per_s):
+        """rehearsal on one device: inbound pieces are held to this rate on the transfer stream (0 = off)"""
+        _chk(lib().dnagpu_multi_set_option(self.h, MULTI_OPT_EMULATE_LINK_GBS, float(gb_per_s)))
+
+    def last_times(self):
+        t = _MultiTimes()
+        _chk(lib().dnagpu_multi_last_times(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _MultiTimes._fields_}
 
     def upload(self, words, n_bases):
         w = np.ascontiguousarray(words, dtype=np.uint64)

@@ -52,6 +52,15 @@ extern "C" const char *dnagpu_strerror(int status)
 
 extern "C" const char *dnagpu_last_error(void) { return g_err; }
 extern "C" int dnagpu_abi_version(void) { return DNAGPU_ABI_VERSION; }
+extern "C" int dnagpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n > 0 ? n : 0;
+}
 
 #ifdef DNAGPU_STAMPS
 static inline const char *diag_env(const char *name) { return getenv(name); }
@@ -136,6 +145,10 @@ struct dnagpu_hist {
     bool sorted;      // the segments are consecutive key ranges (true unless the super-k-mer engine made them)
     u64 extent;       // slots of keys / counts in use: n_distinct, or more when an unordered histogram holds count-0 padding
                       // between segments (0 = n_distinct)
+    // A histogram made of several (dnagpu_hist_parts): the pipelined record exchange counts an owner's buckets group by
+    // group, each group into arrays of its own.  The head then owns no arrays (keys == nullptr); n_distinct / total /
+    // extent are the sums over the parts, the groups of part i come before those of part i + 1 in every ordered read.
+    std::vector<dnagpu_hist *> parts;
 };
 
 // DNAGPU_DEBUG_POISON_POOL: no work buffer starts out zeroed (fresh hipMalloc memory) or holding a
@@ -1520,38 +1533,17 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
 // pieces are copied bucket by bucket into one buffer (equal k-mers share the bucket, so its pieces must form ONE node),
 // then levels 1-2 and the counting as in count_sk.  A skewed set (more than half the k-mers in heavy mid buckets)
 // cannot fall back to the sequence here: all of it is expanded to keys for the ordinary levels instead.
-static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u64 *piece_len, const u32 *piece_bucket, u32 n_pieces,
-                            int k, u64 global_rows, dnagpu_hist *h)
+// rec0 (pool memory; this takes it over and returns it to the pool) = the records of the coarse buckets, bucket after
+// bucket: bucket d = blen[d] records at boff[d] (n_coarse = 2^r0bits entries).  Everything queued on ctx->stream
+// behind whatever filled rec0.
+static int count_sk_received(dnagpu_ctx *ctx, void *rec0, const std::vector<u64> &boff, const std::vector<u64> &blen, const SkGeom &g,
+                             int k, dnagpu_hist *h)
 {
     hipStream_t st = ctx->stream;
     PoolScope ps(ctx);
-    const SkGeom g = sk_geometry(ctx, global_rows, k);
-    const u32 n_coarse = 1u << g.r0bits;
-    std::vector<u64> blen(n_coarse, 0), boff(n_coarse + 1, 0);
-    for (u32 i = 0; i < n_pieces; i++) {
-        if (piece_bucket[i] >= g.c0n || (piece_len[i] && !pieces[i]))
-            return DNAGPU_ERR_BAD_ARG;
-        blen[piece_bucket[i]] += piece_len[i];
-    }
-    for (u32 d = 0; d < n_coarse; d++)
-        boff[d + 1] = boff[d] + blen[d];
-    const u64 n_recs = boff[n_coarse];
-    if (n_recs > 0xFFFFFFFFull)
-        return DNAGPU_ERR_TOO_LARGE;
-    if (n_recs == 0) {
-        h->total = 0;
-        return DNAGPU_OK;
-    }
-    void *rec0 = nullptr;
-    RC_TRY(pool_alloc(ctx, (size_t)n_recs * 16, &rec0));
     ps.ptrs.push_back(rec0);
-    std::vector<u64> fill(boff.begin(), boff.end() - 1);
-    for (u32 i = 0; i < n_pieces; i++)
-        if (piece_len[i]) {
-            HIP_TRY(hipMemcpyAsync(static_cast<char *>(rec0) + fill[piece_bucket[i]] * 16, pieces[i], (size_t)piece_len[i] * 16,
-                                   hipMemcpyDeviceToDevice, st));
-            fill[piece_bucket[i]] += piece_len[i];
-        }
+    const u32 n_coarse = 1u << g.r0bits;
+    const u64 n_recs = boff[n_coarse];
     std::vector<Node> hn(n_coarse);
     for (u32 d = 0; d < n_coarse; d++) {
         memset(&hn[d], 0, sizeof(Node));
@@ -1582,6 +1574,44 @@ static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u6
     }
     RC_TRY(rc);
     return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n_kmers, k, h);
+}
+
+static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u64 *piece_len, const u32 *piece_bucket, u32 n_pieces,
+                            int k, u64 global_rows, dnagpu_hist *h)
+{
+    hipStream_t st = ctx->stream;
+    const SkGeom g = sk_geometry(ctx, global_rows, k);
+    const u32 n_coarse = 1u << g.r0bits;
+    std::vector<u64> blen(n_coarse, 0), boff(n_coarse + 1, 0);
+    for (u32 i = 0; i < n_pieces; i++) {
+        if (piece_bucket[i] >= g.c0n || (piece_len[i] && !pieces[i]))
+            return DNAGPU_ERR_BAD_ARG;
+        blen[piece_bucket[i]] += piece_len[i];
+    }
+    for (u32 d = 0; d < n_coarse; d++)
+        boff[d + 1] = boff[d] + blen[d];
+    const u64 n_recs = boff[n_coarse];
+    if (n_recs > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    if (n_recs == 0) {
+        h->total = 0;
+        return DNAGPU_OK;
+    }
+    void *rec0 = nullptr;
+    RC_TRY(pool_alloc(ctx, (size_t)n_recs * 16, &rec0));
+    std::vector<u64> fill(boff.begin(), boff.end() - 1);
+    for (u32 i = 0; i < n_pieces; i++)
+        if (piece_len[i]) {
+            const hipError_t e = hipMemcpyAsync(static_cast<char *>(rec0) + fill[piece_bucket[i]] * 16, pieces[i], (size_t)piece_len[i] * 16,
+                                                hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) {
+                pool_free(ctx, rec0);
+                set_err("record pieces: %s", hipGetErrorString(e));
+                return DNAGPU_ERR_HIP;
+            }
+            fill[piece_bucket[i]] += piece_len[i];
+        }
+    return count_sk_received(ctx, rec0, boff, blen, g, k, h);
 }
 
 static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, u32 n_fin, const SkHeavy &heavy, u64 n, int k,
@@ -2143,6 +2173,15 @@ extern "C" uint64_t dnagpu_hist_total(const dnagpu_hist *h) { return h ? h->tota
 extern "C" const uint64_t *dnagpu_hist_device_keys(const dnagpu_hist *h) { return h ? h->keys : nullptr; }
 extern "C" uint64_t dnagpu_hist_extent(const dnagpu_hist *h) { return !h ? 0 : (h->extent ? h->extent : h->n_distinct); }
 extern "C" const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h) { return h ? h->counts : nullptr; }
+extern "C" uint32_t dnagpu_hist_parts(const dnagpu_hist *h) { return !h ? 0 : (h->parts.empty() ? 1u : (uint32_t)h->parts.size()); }
+extern "C" const dnagpu_hist *dnagpu_hist_part(const dnagpu_hist *h, uint32_t i)
+{
+    if (!h)
+        return nullptr;
+    if (h->parts.empty())
+        return i == 0 ? h : nullptr;
+    return i < h->parts.size() ? h->parts[i] : nullptr;
+}
 
 // Ascending-key order through the segment directory: groups are gathered on the device into a
 // staging window, then copied to the host.
@@ -2169,6 +2208,24 @@ static int ensure_seg_pre(dnagpu_ctx *ctx, dnagpu_hist *h)
     return DNAGPU_OK;
 }
 
+// groups [first, first + count) of a histogram in its read order = the same range cut along the parts
+template <typename F>
+static int for_parts(dnagpu_hist *h, u64 first, u64 count, F &&f)
+{
+    if (h->parts.empty())
+        return f(h, first, count, (u64)0);
+    u64 base = 0, done = 0;
+    for (dnagpu_hist *p : h->parts) {
+        const u64 lo = std::max(first, base), hi = std::min(first + count, base + p->n_distinct);
+        if (hi > lo) {
+            RC_TRY(f(p, lo - base, hi - lo, done));
+            done += hi - lo;
+        }
+        base += p->n_distinct;
+    }
+    return DNAGPU_OK;
+}
+
 extern "C" int dnagpu_hist_sorted_view(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uint64_t first, uint64_t count,
                                        uint64_t *dev_keys, uint64_t *dev_counts)
 {
@@ -2181,9 +2238,12 @@ extern "C" int dnagpu_hist_sorted_view(dnagpu_ctx *ctx, const dnagpu_hist *h_c, 
     if (count == 0 || (!dev_keys && !dev_counts))
         return DNAGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    RC_TRY(ensure_seg_pre(ctx, h));
-    HIP_TRY(launch_gather_sorted(h->seg_off, h->seg_cnt, h->seg_pre, h->n_segs, first, count, h->keys, h->counts,
-                                 dev_keys, dev_counts, ctx->stream));
+    RC_TRY(for_parts(h, first, count, [&](dnagpu_hist *p, u64 pf, u64 pc, u64 out_at) -> int {
+        RC_TRY(ensure_seg_pre(ctx, p));
+        HIP_TRY(launch_gather_sorted(p->seg_off, p->seg_cnt, p->seg_pre, p->n_segs, pf, pc, p->keys, p->counts,
+                                     dev_keys ? dev_keys + out_at : nullptr, dev_counts ? dev_counts + out_at : nullptr, ctx->stream));
+        return DNAGPU_OK;
+    }));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DNAGPU_OK;
     });
@@ -2201,7 +2261,6 @@ extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uin
     if (count == 0 || (!keys && !counts))
         return DNAGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    RC_TRY(ensure_seg_pre(ctx, h));
     PoolScope ps(ctx);
     const u64 BATCH = (u64)1 << 25;            // 32 Mi groups = 2 x 256 MiB staging
     u64 *sk = nullptr, *sc = nullptr;
@@ -2209,17 +2268,20 @@ extern "C" int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h_c, uin
         RC_TRY(ps.alloc((size_t)std::min(count, BATCH), &sk));
     if (counts)
         RC_TRY(ps.alloc((size_t)std::min(count, BATCH), &sc));
-    for (u64 done = 0; done < count; done += BATCH) {
-        u64 nb = std::min(BATCH, count - done);
-        HIP_TRY(launch_gather_sorted(h->seg_off, h->seg_cnt, h->seg_pre, h->n_segs, first + done, nb, h->keys,
-                                     h->counts, sk, sc, ctx->stream));
-        if (keys)
-            HIP_TRY(hipMemcpyAsync(keys + done, sk, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (counts)
-            HIP_TRY(hipMemcpyAsync(counts + done, sc, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return DNAGPU_OK;
+    return for_parts(h, first, count, [&](dnagpu_hist *p, u64 pf, u64 pc, u64 out_at) -> int {
+        RC_TRY(ensure_seg_pre(ctx, p));
+        for (u64 done = 0; done < pc; done += BATCH) {
+            u64 nb = std::min(BATCH, pc - done);
+            HIP_TRY(launch_gather_sorted(p->seg_off, p->seg_cnt, p->seg_pre, p->n_segs, pf + done, nb, p->keys,
+                                         p->counts, sk, sc, ctx->stream));
+            if (keys)
+                HIP_TRY(hipMemcpyAsync(keys + out_at + done, sk, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (counts)
+                HIP_TRY(hipMemcpyAsync(counts + out_at + done, sc, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        return DNAGPU_OK;
+    });
     });
 }
 
@@ -2234,7 +2296,12 @@ extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64
     u64 *res = nullptr;
     RC_TRY(ps.alloc(4, &res));
     HIP_TRY(hipMemsetAsync(res, 0, 32, ctx->stream));
-    HIP_TRY(launch_hist_summary(h->keys, h->counts, h->extent ? h->extent : h->n_distinct, res, ctx->stream));
+    if (h->parts.empty()) {
+        HIP_TRY(launch_hist_summary(h->keys, h->counts, h->extent ? h->extent : h->n_distinct, res, ctx->stream));
+    } else {
+        for (const dnagpu_hist *p : h->parts)       // (the kernel adds into res: wrapping sums over all parts)
+            HIP_TRY(launch_hist_summary(p->keys, p->counts, p->extent ? p->extent : p->n_distinct, res, ctx->stream));
+    }
     u64 r[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(r, res, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2249,6 +2316,8 @@ extern "C" void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h)
 {
     if (!h)
         return;
+    for (dnagpu_hist *p : h->parts)
+        dnagpu_hist_free(ctx, p);
     if (ctx) {
         pool_free(ctx, h->keys);
         pool_free(ctx, h->counts);
@@ -2316,6 +2385,10 @@ extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, in
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -2358,13 +2431,119 @@ struct RcclApi {
 };
 }  // namespace
 
+// One host thread per rank >= 1, kept for the life of the dnagpu_multi (rank 0's work runs on the caller's thread): a
+// count drives every rank from its own thread because the level loops read counters back between launches.  No
+// exception leaves a worker (std::terminate would take the PostgreSQL backend down): a job that throws marks its rank
+// failed.  If the threads cannot be created the ranks' jobs run one after the other on the caller's thread.
+struct MultiPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    std::vector<int> threw;               // per rank: the job ended in a C++ exception (1 = bad_alloc, 2 = other)
+    unsigned long long gen = 0;
+    int pending = 0;
+    bool stop = false, started = false, serial = false;
+
+    static int run_guarded(const std::function<void(int)> &f, int r) noexcept
+    {
+        try {
+            f(r);
+            return 0;
+        } catch (const std::bad_alloc &) {
+            return 1;
+        } catch (...) {
+            return 2;
+        }
+    }
+    void worker(int r)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *f = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || gen != seen; });
+                if (stop)
+                    return;
+                seen = gen;
+                f = job;
+            }
+            const int t = run_guarded(*f, r);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                threw[(size_t)r] = t;
+                if (--pending == 0)
+                    cv_done.notify_all();
+            }
+        }
+    }
+    void start(int n) noexcept
+    {
+        if (started)
+            return;
+        started = true;
+        try {
+            threw.assign((size_t)n, 0);
+            th.reserve((size_t)n);
+            for (int r = 1; r < n; r++)
+                th.emplace_back(&MultiPool::worker, this, r);
+        } catch (...) {
+            shutdown();                       // joins the threads that did start
+            serial = true;
+        }
+    }
+    // runs f(r) for r = 0 .. n-1, rank 0 here; returns 0, or DNAGPU_ERR_OOM / DNAGPU_ERR_INTERNAL if a job threw
+    int run(int n, const std::function<void(int)> &f) noexcept
+    {
+        start(n);
+        int bad = 0;
+        if (serial || n == 1) {
+            for (int r = 0; r < n; r++)
+                bad = std::max(bad, run_guarded(f, r));
+        } else {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                job = &f;
+                pending = n - 1;
+                gen++;
+            }
+            cv_go.notify_all();
+            bad = run_guarded(f, 0);
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+            for (int r = 1; r < n; r++)
+                bad = std::max(bad, threw[(size_t)r]);
+        }
+        return bad == 0 ? DNAGPU_OK : (bad == 1 ? DNAGPU_ERR_OOM : DNAGPU_ERR_INTERNAL);
+    }
+    void shutdown() noexcept
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (std::thread &t : th)
+            if (t.joinable())
+                t.join();
+        th.clear();
+        stop = false;
+    }
+};
+
 struct dnagpu_multi {
+    MultiPool workers;
     int n;
     std::vector<int> dev;
     std::vector<dnagpu_ctx *> ctx;
     bool rccl;
     RcclApi api;
     std::vector<ncclComm_t> comms;
+    dnagpu_multi_times last{};            // host clock of the most recent dnagpu_count_multi_unordered
+    std::vector<hipStream_t> xfer;        // per rank: the stream its inbound record copies are queued on
+    int parts = DNAGPU_MULTI_DEFAULT_PARTS;   // bucket groups per owner of the pipelined exchange
+    double emulate_gbs = 0;               // rehearsal: same-device "transfers" are held to this rate (0 = off)
 };
 
 struct dnagpu_multi_dna {
@@ -2377,6 +2556,12 @@ extern "C" void dnagpu_multi_destroy(dnagpu_multi *m)
 {
     if (!m)
         return;
+    m->workers.shutdown();
+    for (size_t r = 0; r < m->xfer.size(); r++)
+        if (hipSetDevice(m->ctx[r]->device) == hipSuccess) {
+            (void)hipStreamSynchronize(m->xfer[r]);
+            (void)hipStreamDestroy(m->xfer[r]);
+        }
     for (size_t r = 0; r < m->comms.size(); r++)
         if (m->comms[r])
             m->api.CommDestroy(m->comms[r]);
@@ -2443,10 +2628,16 @@ extern "C" int dnagpu_multi_init(const int *devices, int n_gpus, int transport, 
             if (nr != ncclSuccess) {
                 set_err("ncclCommInitAll: %s", m->api.GetErrorString(nr));
                 m->comms.clear();
-                dnagpu_multi_destroy(m);
-                return DNAGPU_ERR_HIP;
+                (void)hipGetLastError();
+                if (transport == DNAGPU_MULTI_RCCL) {
+                    dnagpu_multi_destroy(m);
+                    return DNAGPU_ERR_HIP;
+                }
+                // DNAGPU_MULTI_AUTO: "RCCL when ... the library loads, else copies" -- a communicator that cannot be made
+                // (e.g. another ROCm runtime already in the process) leaves the copy transport
+            } else {
+                m->rccl = true;
             }
-            m->rccl = true;
         }
     }
     *out = m;
@@ -2460,6 +2651,13 @@ extern "C" dnagpu_ctx *dnagpu_multi_ctx(dnagpu_multi *m, int rank)
     return (m && rank >= 0 && rank < m->n) ? m->ctx[(size_t)rank] : nullptr;
 }
 extern "C" const char *dnagpu_multi_transport(const dnagpu_multi *m) { return !m ? "" : (m->rccl ? "rccl" : "copy"); }
+extern "C" int dnagpu_multi_last_times(const dnagpu_multi *m, dnagpu_multi_times *out)
+{
+    if (!m || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    *out = m->last;
+    return DNAGPU_OK;
+}
 
 extern "C" void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d)
 {
@@ -2746,18 +2944,21 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     // only run concurrently when each is driven by its own thread (device selection is per thread)
     std::vector<int> rcs((size_t)m->n, DNAGPU_OK);
     std::vector<std::string> errs((size_t)m->n);
-    auto work = [&](int r) {
+    const std::function<void(int)> work = [&](int r) {
         rcs[(size_t)r] = dnagpu_count_kmers_owned(m->ctx[(size_t)r], dna->view[(size_t)r], k, first, count, r, m->n,
                                                  &hists[r]);
         if (rcs[(size_t)r] != DNAGPU_OK)
             errs[(size_t)r] = dnagpu_last_error();                // the error text is per thread
     };
-    std::vector<std::thread> th;
-    for (int r = 1; r < m->n; r++)
-        th.emplace_back(work, r);
-    work(0);
-    for (std::thread &t : th)
-        t.join();
+    const int wrc = m->workers.run(m->n, work);
+    if (wrc != DNAGPU_OK) {
+        set_err("a rank's count ended in a C++ exception");
+        for (int q = 0; q < m->n; q++) {
+            dnagpu_hist_free(m->ctx[(size_t)q], hists[q]);
+            hists[q] = nullptr;
+        }
+        return wrc;
+    }
     for (int r = 0; r < m->n; r++)
         if (rcs[(size_t)r] != DNAGPU_OK) {
             set_err("rank %d: %s", r, errs[(size_t)r].c_str());
@@ -2771,11 +2972,68 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     });
 }
 
-// The same count without any order promise, for long k-mers (k >= 23): the record exchange of sharded.py from one process.
+// ---- the same count without any order promise, for long k-mers (k >= 23): the record exchange from one process.
 // Rank r cuts the records of the rows that start in its own chunk (one word of halo from its neighbour), every coarse
-// bucket's pieces are pulled by the bucket's owner (peer copies inside dnagpu_count_records: 16-byte records, 1.8 B per
-// k-mer at k = 31; nothing is gathered and no rank sweeps rows of another), and the owner counts them.
-// hists[r] = the groups of rank r's buckets: disjoint, in no key order.
+// bucket's pieces are pulled by the bucket's owner (peer copies of 16-byte records, 1.8 B per k-mer at k = 31; nothing is
+// gathered and no rank sweeps rows of another), and the owner counts them.  The exchange is PIPELINED with the count: an
+// owner's buckets are cut into `parts` groups; all copies are queued at once on the owner's transfer stream, group after
+// group with an event behind each, and the counting of group g (on the context's stream) waits for event g only -- the
+// pieces of group g + 1 arrive while group g is counted.  hists[r] = the groups of rank r's buckets (a histogram of
+// `parts` parts): disjoint between ranks, in no key order.
+
+// rehearsal aid: holds a stream for `ticks` of the 100 MHz wall clock (the time a copy of that size would take on a link
+// of the emulated bandwidth); one wave, every lane leaves the loop when the clock passes the deadline
+__global__ __launch_bounds__(64) void link_delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value)
+{
+    if (!m)
+        return DNAGPU_ERR_BAD_ARG;
+    switch (option) {
+    case DNAGPU_MULTI_OPT_PARTS:
+        if (value < 1 || value > DNAGPU_MULTI_MAX_PARTS)
+            return DNAGPU_ERR_BAD_ARG;
+        m->parts = (int)value;
+        return DNAGPU_OK;
+    case DNAGPU_MULTI_OPT_EMULATE_LINK_GBS:
+        if (value < 0)
+            return DNAGPU_ERR_BAD_ARG;
+        m->emulate_gbs = value;
+        return DNAGPU_OK;
+    }
+    return DNAGPU_ERR_BAD_ARG;
+}
+
+namespace {
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+struct EventSet {                               // timing events of one owner, destroyed with the scope
+    std::vector<hipEvent_t> ev;
+    ~EventSet()
+    {
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+    }
+    hipError_t make(hipEvent_t *out)
+    {
+        hipEvent_t e;
+        const hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess)
+            return r;
+        ev.push_back(e);
+        *out = e;
+        return hipSuccess;
+    }
+};
+}  // namespace
+
 extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                                             dnagpu_hist **hists)
 {
@@ -2784,23 +3042,32 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
         return DNAGPU_ERR_BAD_ARG;
     for (int r = 0; r < m->n; r++)
         hists[r] = nullptr;
+    m->last = dnagpu_multi_times{};
     RC_TRY(check_range(dna->view[0], k, first, count));
     if (k < sk_min_k() || count == 0)
         return dnagpu_count_multi(m, dna, k, first, count, hists);         // (short k-mers: the ordered paths)
+    const auto t_call = std::chrono::steady_clock::now();
     const int W = m->n;
+    // the owners' transfer streams (one per rank, made on first use)
+    while ((int)m->xfer.size() < W) {
+        const int r = (int)m->xfer.size();
+        hipStream_t xs = nullptr;
+        HIP_TRY(hipSetDevice(m->ctx[(size_t)r]->device));
+        HIP_TRY(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
+        m->xfer.push_back(xs);
+    }
     std::vector<dnagpu_records *> recs((size_t)W, nullptr);
     std::vector<int> rcs((size_t)W, DNAGPU_OK);
     std::vector<std::string> errs((size_t)W);
-    auto run_all = [&](auto &&work) {
-        std::vector<std::thread> th;
-        for (int r = 1; r < W; r++)
-            th.emplace_back(work, r);
-        work(0);
-        for (std::thread &t : th)
-            t.join();
+    std::vector<double> t_rec((size_t)W, 0.0), t_cnt((size_t)W, 0.0), t_xfer((size_t)W, 0.0), t_hidden((size_t)W, 0.0);
+    std::vector<u64> moved((size_t)W, 0);
+    auto fail = [&](int r, int rc, const char *what) {
+        rcs[(size_t)r] = rc;
+        errs[(size_t)r] = what;
     };
     // ---- every rank: the records of its own rows
-    run_all([&](int r) {
+    const std::function<void(int)> cut = [&](int r) {
+        const auto t0 = std::chrono::steady_clock::now();
         dnagpu_ctx *c = m->ctx[(size_t)r];
         const u64 w_lo = std::min((u64)r * dna->per, dna->n_words), w_hi = std::min((u64)(r + 1) * dna->per, dna->n_words);
         const u64 row_lo = std::max<u64>(first, w_lo * 32), row_hi = std::min<u64>(first + count, w_hi * 32);
@@ -2812,25 +3079,27 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
             e = m->dev[(size_t)src] == m->dev[(size_t)r] ? hipMemcpyAsync(to, from, 8, hipMemcpyDeviceToDevice, c->stream)
                                                         : hipMemcpyPeerAsync(to, m->dev[(size_t)r], from, m->dev[(size_t)src], 8, c->stream);
         }
-        if (e != hipSuccess) {
-            rcs[(size_t)r] = DNAGPU_ERR_HIP;
-            errs[(size_t)r] = hipGetErrorString(e);
-            return;
-        }
+        if (e != hipSuccess)
+            return fail(r, DNAGPU_ERR_HIP, hipGetErrorString(e));
         rcs[(size_t)r] = dnagpu_sk_records(c, dna->view[(size_t)r], k, row_hi > row_lo ? row_lo : 0, row_hi > row_lo ? row_hi - row_lo : 0,
                                            count, &recs[(size_t)r]);
         if (rcs[(size_t)r] != DNAGPU_OK)
             errs[(size_t)r] = dnagpu_last_error();
-    });
-    int rc = DNAGPU_OK;
+        t_rec[(size_t)r] = ms_since(t0);
+    };
+    int rc = m->workers.run(W, cut);
+    if (rc != DNAGPU_OK)
+        set_err("a rank's record pass ended in a C++ exception");
     for (int r = 0; r < W && rc == DNAGPU_OK; r++)
         if (rcs[(size_t)r] != DNAGPU_OK) {
             set_err("rank %d (records): %s", r, errs[(size_t)r].c_str());
             rc = rcs[(size_t)r];
         }
-    // ---- every owner: its buckets' pieces from all ranks
+    // ---- every owner: its buckets' pieces from all ranks, group by group, counted as they land
     if (rc == DNAGPU_OK) {
+        const SkGeom g = sk_geometry(m->ctx[0], count, k);
         const u32 nb = dnagpu_records_buckets(recs[0]);
+        const u32 n_coarse = 1u << g.r0bits;
         // owners: contiguous bucket ranges balanced by the records the buckets hold on all ranks (shard_math.py:
         // bucket_owner_ranges_weighted -- a bucket goes to the side its middle falls on)
         std::vector<u64> wgt(nb, 0);
@@ -2840,48 +3109,202 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
                 wgt[b] += recs[(size_t)r]->off[b + 1] - recs[(size_t)r]->off[b];
                 wtotal += recs[(size_t)r]->off[b + 1] - recs[(size_t)r]->off[b];
             }
-        std::vector<u32> cut((size_t)W + 1, 0);
-        cut[(size_t)W] = nb;
+        // cuts[j] for j = 0 .. W * P: owner o's group p = buckets [cuts[o * P + p], cuts[o * P + p + 1])
+        const int P = std::max(1, std::min(m->parts, (int)DNAGPU_MULTI_MAX_PARTS));
+        const int WP = W * P;
+        std::vector<u32> cuts((size_t)WP + 1, 0);
+        cuts[(size_t)WP] = nb;
         if (wtotal == 0) {
-            for (int o = 1; o < W; o++)
-                cut[(size_t)o] = (u32)(((u64)o * nb + (u64)W - 1) / (u64)W);
+            for (int j = 1; j < WP; j++)
+                cuts[(size_t)j] = (u32)(((u64)j * nb + (u64)WP - 1) / (u64)WP);
         } else {
-            u64 run = 0;
-            u32 b = 0;
-            for (int o = 1; o < W; o++) {
-                const double target = (double)wtotal * o / W;
-                while (b < nb && (double)run + (double)wgt[b] / 2 <= target) {
-                    run += wgt[b];
-                    b++;
+            // owners first (the rule the process-per-GPU path uses), then every owner's range into P groups the same way
+            std::vector<u32> ocut((size_t)W + 1, 0);
+            ocut[(size_t)W] = nb;
+            auto split = [&](u32 lo, u32 hi, int ways, u32 *out /* ways + 1 entries, out[0] = lo, out[ways] = hi */) {
+                u64 tot = 0;
+                for (u32 b = lo; b < hi; b++)
+                    tot += wgt[b];
+                out[0] = lo;
+                out[ways] = hi;
+                u64 run = 0;
+                u32 b = lo;
+                for (int j = 1; j < ways; j++) {
+                    const double target = (double)tot * j / ways;
+                    while (b < hi && (double)run + (double)wgt[b] / 2 <= target) {
+                        run += wgt[b];
+                        b++;
+                    }
+                    out[j] = b;
                 }
-                cut[(size_t)o] = b;
-            }
+            };
+            split(0, nb, W, ocut.data());
+            for (int o = 0; o < W; o++)
+                split(ocut[(size_t)o], std::max(ocut[(size_t)o + 1], ocut[(size_t)o]), P, &cuts[(size_t)o * P]);
         }
-        run_all([&](int o) {
-            const u32 b_lo = cut[(size_t)o], b_hi = std::max(cut[(size_t)o + 1], cut[(size_t)o]);
-            std::vector<const void *> ptr;
-            std::vector<u64> len;
-            std::vector<u32> bk;
-            for (int src = 0; src < W; src++)
-                for (u32 b = b_lo; b < b_hi; b++) {
-                    const dnagpu_records *rr = recs[(size_t)src];
-                    const u64 n_b = rr->off[b + 1] - rr->off[b];
-                    if (n_b) {
-                        ptr.push_back(static_cast<const char *>(rr->recs) + rr->off[b] * 16);
-                        len.push_back(n_b);
-                        bk.push_back(b);
+        m->last.parts = P;
+        const std::function<void(int)> own = [&](int o) {
+            const auto t0 = std::chrono::steady_clock::now();
+            dnagpu_ctx *c = m->ctx[(size_t)o];
+            hipStream_t xs = m->xfer[(size_t)o];
+            hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess)
+                return fail(o, DNAGPU_ERR_HIP, hipGetErrorString(e));
+            dnagpu_hist *head = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, false};
+            if (!head)
+                return fail(o, DNAGPU_ERR_OOM, "host allocation failed");
+            hists[o] = head;
+            EventSet evs;
+            hipEvent_t x0 = nullptr, x1 = nullptr, c0 = nullptr;
+            std::vector<hipEvent_t> landed((size_t)P, nullptr);
+            std::vector<void *> bufs((size_t)P, nullptr);
+            std::vector<std::vector<u64>> boffs((size_t)P), blens((size_t)P);
+            auto drop = [&](int rc_, const char *what) {          // error exit: nothing of this owner's buffers is in flight afterwards
+                (void)hipStreamSynchronize(xs);
+                (void)hipStreamSynchronize(c->stream);
+                for (void *b : bufs)
+                    pool_free(c, b);
+                fail(o, rc_, what);
+            };
+            hipEvent_t ready = nullptr;
+            e = evs.make(&x0);
+            if (e == hipSuccess) e = evs.make(&x1);
+            if (e == hipSuccess) e = evs.make(&c0);
+            if (e == hipSuccess) e = evs.make(&ready);
+            for (int p = 0; p < P && e == hipSuccess; p++)
+                e = evs.make(&landed[(size_t)p]);
+            if (e != hipSuccess)
+                return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+            // ---- every group's landing buffer
+            for (int p = 0; p < P; p++) {
+                const u32 b_lo = cuts[(size_t)o * P + p], b_hi = std::max(cuts[(size_t)o * P + p + 1], b_lo);
+                std::vector<u64> &blen = blens[(size_t)p], &boff = boffs[(size_t)p];
+                blen.assign(n_coarse, 0);
+                boff.assign((size_t)n_coarse + 1, 0);
+                for (u32 b = b_lo; b < b_hi; b++)
+                    blen[b] = wgt[b];
+                for (u32 d = 0; d < n_coarse; d++)
+                    boff[d + 1] = boff[d] + blen[d];
+                const u64 n_recs = boff[n_coarse];
+                if (n_recs > 0xFFFFFFFFull)
+                    return drop(DNAGPU_ERR_TOO_LARGE, "too many records for one owner");
+                if (n_recs) {
+                    const int arc = pool_alloc(c, (size_t)n_recs * 16, &bufs[(size_t)p]);
+                    if (arc != DNAGPU_OK)
+                        return drop(arc, dnagpu_last_error());
+                }
+            }
+            // The pool orders reuse on the context's stream only (and poisons there when asked to): the transfer stream
+            // starts behind everything queued on it so far -- the owner's own record pass included, whose pieces are read
+            // from this device; the other ranks' passes were synchronised by dnagpu_sk_records.
+            e = hipEventRecord(ready, c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(xs, ready, 0);
+            if (e == hipSuccess) e = hipEventRecord(x0, xs);
+            if (e != hipSuccess)
+                return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+            // ---- all copies, group after group, an event behind each group
+            for (int p = 0; p < P; p++) {
+                const u32 b_lo = cuts[(size_t)o * P + p], b_hi = std::max(cuts[(size_t)o * P + p + 1], b_lo);
+                const std::vector<u64> &boff = boffs[(size_t)p];
+                if (bufs[(size_t)p]) {
+                    u64 delay_bytes = 0;
+                    for (u32 b = b_lo; b < b_hi; b++) {
+                        u64 at = boff[b];
+                        for (int q = 0; q < W; q++) {
+                            const int src = (o + q) % W;             // own pieces first, then round the ranks: spreads the link load
+                            const dnagpu_records *rr = recs[(size_t)src];
+                            const u64 n_b = rr->off[b + 1] - rr->off[b];
+                            if (!n_b)
+                                continue;
+                            char *to = static_cast<char *>(bufs[(size_t)p]) + at * 16;
+                            const char *from = static_cast<const char *>(rr->recs) + rr->off[b] * 16;
+                            if (m->dev[(size_t)src] == m->dev[(size_t)o])
+                                e = hipMemcpyAsync(to, from, (size_t)n_b * 16, hipMemcpyDeviceToDevice, xs);
+                            else
+                                e = hipMemcpyPeerAsync(to, m->dev[(size_t)o], from, m->dev[(size_t)src], (size_t)n_b * 16, xs);
+                            if (e != hipSuccess)
+                                return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+                            if (src != o) {
+                                moved[(size_t)o] += n_b * 16;
+                                delay_bytes += n_b * 16;
+                            }
+                            at += n_b;
+                        }
+                    }
+                    if (m->emulate_gbs > 0 && delay_bytes) {
+                        // rehearsal on one device: the group's inbound bytes at the emulated rate, on the transfer stream
+                        const double us = (double)delay_bytes / (m->emulate_gbs * 1e3);
+                        const unsigned long long ticks = (unsigned long long)std::min(us, 50000.0) * 100ull;
+                        hipLaunchKernelGGL(link_delay_kernel, dim3(1), dim3(64), 0, xs, ticks);
                     }
                 }
-            rcs[(size_t)o] = dnagpu_count_records(m->ctx[(size_t)o], ptr.data(), len.data(), bk.data(), (u32)ptr.size(), k, count,
-                                                  &hists[o]);
-            if (rcs[(size_t)o] != DNAGPU_OK)
-                errs[(size_t)o] = dnagpu_last_error();
-        });
+                e = hipEventRecord(landed[(size_t)p], xs);
+                if (e != hipSuccess)
+                    return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+            }
+            e = hipEventRecord(x1, xs);
+            if (e == hipSuccess) e = hipEventRecord(c0, c->stream);
+            if (e != hipSuccess)
+                return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+            // ---- count group p behind its event
+            prof_begin(c);
+            for (int p = 0; p < P; p++) {
+                if (!bufs[(size_t)p])
+                    continue;
+                e = hipStreamWaitEvent(c->stream, landed[(size_t)p], 0);
+                if (e != hipSuccess)
+                    return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+                dnagpu_hist *part = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, false};
+                if (!part)
+                    return drop(DNAGPU_ERR_OOM, "host allocation failed");
+                void *buf = bufs[(size_t)p];
+                bufs[(size_t)p] = nullptr;                        // (count_sk_received takes the buffer over)
+                const int crc = count_sk_received(c, buf, boffs[(size_t)p], blens[(size_t)p], g, k, part);
+                if (crc != DNAGPU_OK) {
+                    delete part;
+                    return drop(crc, dnagpu_last_error());
+                }
+                head->parts.push_back(part);
+                head->n_distinct += part->n_distinct;
+                head->total += part->total;
+                head->extent += part->extent ? part->extent : part->n_distinct;
+            }
+            prof_end(c);
+            e = hipStreamSynchronize(xs);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess)
+                return drop(DNAGPU_ERR_HIP, hipGetErrorString(e));
+            float x_ms = 0, c_at = 0;
+            (void)hipEventElapsedTime(&x_ms, x0, x1);             // first copy queued -> last piece landed
+            (void)hipEventElapsedTime(&c_at, x0, c0);             // ... -> the owner's stream was free to count
+            t_xfer[(size_t)o] = x_ms;
+            // the counting starts when the first group has landed; what the transfer stream did after that ran beside it
+            float first_ms = 0;
+            (void)hipEventElapsedTime(&first_ms, x0, landed[0]);
+            t_hidden[(size_t)o] = std::max(0.0f, x_ms - std::max(first_ms, c_at));
+            if (head->parts.size() == 1) {                        // one group: a plain histogram, no head
+                dnagpu_hist *only = head->parts[0];
+                head->parts.clear();
+                delete head;
+                hists[o] = only;
+            }
+            t_cnt[(size_t)o] = ms_since(t0);
+        };
+        const auto t_own = std::chrono::steady_clock::now();
+        rc = m->workers.run(W, own);
+        if (rc != DNAGPU_OK)
+            set_err("an owner's count ended in a C++ exception");
         for (int r = 0; r < W && rc == DNAGPU_OK; r++)
             if (rcs[(size_t)r] != DNAGPU_OK) {
                 set_err("rank %d (count): %s", r, errs[(size_t)r].c_str());
                 rc = rcs[(size_t)r];
             }
+        m->last.records_ms = *std::max_element(t_rec.begin(), t_rec.end());
+        m->last.exchange_ms = *std::max_element(t_xfer.begin(), t_xfer.end());
+        m->last.hidden_ms = *std::min_element(t_hidden.begin(), t_hidden.end());
+        m->last.count_ms = ms_since(t_own);
+        for (int r = 0; r < W; r++)
+            m->last.bytes_moved += moved[(size_t)r];
     }
     for (int r = 0; r < W; r++) {
         (void)hipSetDevice(m->ctx[(size_t)r]->device);
@@ -2892,6 +3315,7 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
         }
     }
     (void)hipSetDevice(m->ctx[0]->device);
+    m->last.total_ms = ms_since(t_call);
     return rc;
     });
 }

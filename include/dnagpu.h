@@ -54,6 +54,9 @@ const char *dnagpu_strerror(int status);
 /* detail text of the most recent failing call on the calling thread (HIP error string, etc.) */
 const char *dnagpu_last_error(void);
 int dnagpu_abi_version(void);
+/* Number of HIP devices this process can use (0 when there is none or the runtime cannot start).  Does not create a
+ * context. */
+int dnagpu_device_count(void);
 
 /* ---- context ------------------------------------------------------------------------------ */
 typedef struct dnagpu_ctx dnagpu_ctx;
@@ -200,6 +203,13 @@ uint64_t dnagpu_hist_extent(const dnagpu_hist *h);     /* slots of the two devic
 /* counts are 32-bit in device memory (one call covers at most 2^32 - 1 rows); dnagpu_hist_download
  * widens them to the 64-bit count(*) of SQL */
 const uint32_t *dnagpu_hist_device_counts(const dnagpu_hist *h);
+/* A histogram may consist of several PARTS, each with device arrays of its own (the pipelined multi-GPU count makes
+ * them: one per bucket group of an owner).  dnagpu_hist_parts is 1 for every other histogram.  For a histogram of
+ * several parts dnagpu_hist_device_keys / _counts are NULL -- walk the parts instead (dnagpu_hist_part(h, i): a
+ * borrowed view, freed with h); distinct / total / extent / summary / download / sorted_view cover all parts, the
+ * groups of part i before those of part i + 1. */
+uint32_t dnagpu_hist_parts(const dnagpu_hist *h);
+const dnagpu_hist *dnagpu_hist_part(const dnagpu_hist *h, uint32_t i);
 /* Copies groups [first, first+count) of the ASCENDING-KEY order to host arrays (either may be
  * NULL). */
 int dnagpu_hist_download(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t first, uint64_t count,
@@ -315,10 +325,37 @@ int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint
  * shorter ones go through dnagpu_count_multi): the record exchange above from one process.  Nothing is gathered:
  * rank r cuts the super-k-mer records of the rows that start in its own chunk, the owner of a coarse bucket pulls the
  * bucket's pieces from every rank (peer copies of 16-byte records, 1.8 B per k-mer at k = 31) and counts them.
- * hists[r] = the groups of rank r's buckets: disjoint between ranks, dnagpu_hist_is_sorted == 0, sum of
- * dnagpu_hist_total = count. */
+ * The exchange is pipelined with the count: an owner's buckets travel in DNAGPU_MULTI_OPT_PARTS groups on a transfer
+ * stream of their own and group g is counted while group g + 1 is still in flight.
+ * hists[r] = the groups of rank r's buckets (a histogram of up to that many parts, dnagpu_hist_parts): disjoint between
+ * ranks, dnagpu_hist_is_sorted == 0, sum of dnagpu_hist_total = count. */
 int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                                  dnagpu_hist **hists);
+
+/* Options of a dnagpu_multi (dnagpu_multi_set_option):
+ *   DNAGPU_MULTI_OPT_PARTS             bucket groups per owner of dnagpu_count_multi_unordered's pipelined exchange, 1 ..
+ *                                      DNAGPU_MULTI_MAX_PARTS (1 = all pieces first, then one count)
+ *   DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  rehearsal aid for ranks that share one device: every group of inbound pieces is
+ *                                      followed, on the transfer stream, by the time the same bytes would take at this
+ *                                      many GB/s (0 = off, the default) -- timing only, results are unaffected */
+#define DNAGPU_MULTI_OPT_PARTS             1
+#define DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  2
+#define DNAGPU_MULTI_MAX_PARTS             8
+#define DNAGPU_MULTI_DEFAULT_PARTS         2
+int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value);
+
+/* Host wall-clock milliseconds of the most recent dnagpu_count_multi_unordered call on m, per phase, the slowest rank of
+ * each phase: records_ms = every rank cutting the records of its own rows, exchange_ms = the owners' copies of their
+ * buckets' pieces (until the last piece of the slowest owner has landed; the part of it that ran while the owner was
+ * already counting earlier buckets is hidden_ms; both from HIP events on the owner's streams), count_ms = the owners'
+ * phase as a whole (copies queued, groups counted as they land), total_ms = the whole call.  All 0 before the first call
+ * or when the call took another path (short k-mers). */
+typedef struct dnagpu_multi_times {
+    double records_ms, exchange_ms, hidden_ms, count_ms, total_ms;
+    uint64_t bytes_moved;     /* record bytes copied between ranks (pieces that stayed on their rank not counted) */
+    int parts;                /* bucket groups per owner of the pipelined exchange */
+} dnagpu_multi_times;
+int dnagpu_multi_last_times(const dnagpu_multi *m, dnagpu_multi_times *out);
 
 /* ---- batched operators over arrays of keys (bulk scans of stored kmer columns) -------------- */
 

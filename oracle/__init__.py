@@ -53,6 +53,8 @@ def lib():
         L.orc_count_keys.argtypes = [u64p, C.c_uint64, C.POINTER(u64p), C.POINTER(u64p), u64p]
         L.orc_count_kmers.argtypes = [u64p, C.c_uint64, C.c_int, C.c_int, C.POINTER(u64p),
                                       C.POINTER(u64p), u64p]
+        L.orc_count_kmers_slice.argtypes = [u64p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(u64p),
+                                            C.POINTER(u64p), u64p]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_hist_summary.argtypes = [u64p, u64p, C.c_uint64, u64p, u64p, u64p]
         L.orc_pair_mix.restype = C.c_uint64
@@ -206,6 +208,14 @@ def count_kmers(words, n_bases, k, faithful=False):
     w = np.ascontiguousarray(words, dtype=np.uint64)
     pk, pc, d = u64p(), u64p(), C.c_uint64()
     _chk(lib().orc_count_kmers(_p(w), n_bases, k, int(faithful), C.byref(pk), C.byref(pc), C.byref(d)))
+    return _take(pk, pc, d.value)
+
+
+def count_kmers_slice(words, n_bases, k, slice_, n_slices):
+    """the groups of one slice of the key space (disjoint between slices, union = count_kmers)"""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    pk, pc, d = u64p(), u64p(), C.c_uint64()
+    _chk(lib().orc_count_kmers_slice(_p(w), n_bases, k, slice_, n_slices, C.byref(pk), C.byref(pc), C.byref(d)))
     return _take(pk, pc, d.value)
 
 

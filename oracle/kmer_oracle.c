@@ -449,6 +449,45 @@ int orc_count_kmers(const uint64_t *words, uint64_t n_bases, int k, int faithful
     return rc;
 }
 
+/* The same GROUP BY restricted to the k-mers of one slice of the key space: slice = (mix(key) >> 32) * n_slices
+ * >> 32 with mix = splitmix64 -- every copy of a k-mer falls into the same slice, so the groups of the n_slices
+ * slices are disjoint and their union is orc_count_kmers' result; total / distinct / unique / checksum of the whole
+ * histogram are the sums over the slices.  This is how tools/make_digests.py counts sequences whose 8-byte keys would
+ * not fit this container's memory at once (3 Gbase: 24 GB of keys).  Extraction is the word-arithmetic form
+ * (cross-checked against the faithful per-base form in tests/test_oracle_golden.py); the aggregate is
+ * orc_count_keys (kmer_hash + kmer_eq, dna.c:722-735, 655-668). */
+int orc_count_kmers_slice(const uint64_t *words, uint64_t n_bases, int k, uint32_t slice, uint32_t n_slices,
+                          uint64_t **out_keys, uint64_t **out_counts, uint64_t *n_distinct)
+{
+    uint64_t total;
+    int rc = orc_generate_kmers_count(n_bases, k, &total);
+    if (rc)
+        return rc;
+    if (n_slices == 0 || slice >= n_slices)
+        return ORC_ERR_NOMEM;
+    uint64_t nw = orc_dna_num_words(n_bases);
+    uint64_t cap = total / n_slices + total / (8 * (uint64_t)n_slices) + 65536, n = 0;
+    uint64_t *keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    if (!keys)
+        return ORC_ERR_NOMEM;
+    for (uint64_t p = 0; p < total; p++) {
+        uint64_t key = window_at(words, nw, p, k);
+        uint64_t s = ((orc_splitmix64(key) >> 32) * (uint64_t)n_slices) >> 32;
+        if (s != slice)
+            continue;
+        if (n == cap) {
+            cap += cap / 2;
+            uint64_t *g = (uint64_t *)realloc(keys, cap * sizeof(uint64_t));
+            if (!g) { free(keys); return ORC_ERR_NOMEM; }
+            keys = g;
+        }
+        keys[n++] = key;
+    }
+    rc = orc_count_keys(keys, n, out_keys, out_counts, n_distinct);
+    free(keys);
+    return rc;
+}
+
 void orc_free(void *p) { free(p); }
 
 /* order-independent digest of one (key, count) group */

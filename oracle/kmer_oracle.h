@@ -105,6 +105,9 @@ int orc_count_keys(const uint64_t *keys, uint64_t n, uint64_t **out_keys, uint64
                    uint64_t *n_distinct);
 int orc_count_kmers(const uint64_t *words, uint64_t n_bases, int k, int faithful,
                     uint64_t **out_keys, uint64_t **out_counts, uint64_t *n_distinct);
+/* the groups of slice `slice` of n_slices of the key space (disjoint between slices; see kmer_oracle.c) */
+int orc_count_kmers_slice(const uint64_t *words, uint64_t n_bases, int k, uint32_t slice, uint32_t n_slices,
+                          uint64_t **out_keys, uint64_t **out_counts, uint64_t *n_distinct);
 void orc_free(void *p);
 
 /* total / distinct / unique summary (test.sql:107-119) and an order-independent checksum */

@@ -1,6 +1,8 @@
 """GPU parity: the HIP back-end (through the C-ABI, libdnagpu.so) against the CPU oracle on the same
 seeded inputs, against the reference's golden vectors, and -- at BASELINE.json sizes -- through
 size-independent properties.  Bit-exact: everything on this path is integer work."""
+import os
+
 import numpy as np
 import pytest
 
@@ -995,14 +997,18 @@ def test_count_multi_one_process(pkg, n_ranks):
             m.dna_free(d)
 
 
-@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
-def test_count_multi_unordered_one_process(pkg, n_ranks):
+@pytest.mark.parametrize("n_ranks,parts", [(1, 1), (2, 2), (3, 3), (8, 2), (8, 1), (2, 8)])
+def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
     """dnagpu_count_multi_unordered: the record exchange from one process (every rank on device 0: chunk residency, the
-    halo word, per-rank records, the owners' pulls of their buckets' pieces are the product code).  The ranks' groups are
-    disjoint and together the oracle's histogram; short k-mers take the ordered paths."""
+    halo word, per-rank records, the owners' pulls of their buckets' pieces on the transfer stream, the counting of a
+    bucket group behind its event are the product code).  The ranks' groups are disjoint and together the oracle's
+    histogram, whatever the number of bucket groups per owner; short k-mers take the ordered paths."""
     n, seed = 3_000_017, 0xD2A0003
     words = orc.synth_words(seed, n)
     with pkg.Multi([0] * n_ranks, pkg.MULTI_COPY) as m:
+        m.set_parts(parts)
+        if parts == 2 and n_ranks == 2:
+            m.emulate_link(50.0)            # the rehearsal delay kernel on the transfer stream: timing only
         for make in ("synth", "upload"):
             d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
             for k, first, count in ((31, 0, None), (27, 1000, 2_000_000), (23, 31, None), (32, 0, 1_234_567), (8, 0, None)):
@@ -1012,11 +1018,47 @@ def test_count_multi_unordered_one_process(pkg, n_ranks):
                 gc = np.concatenate([h.download()[1] for h in hs])
                 assert sum(h.total for h in hs) == int(oc.sum())
                 order = np.argsort(gk, kind="stable")
-                assert_same(gk[order], ok, f"multi unordered {n_ranks} ranks ({make}) k={k} keys")
-                assert_same(gc[order], oc, f"multi unordered {n_ranks} ranks ({make}) k={k} counts")
+                assert_same(gk[order], ok, f"multi unordered {n_ranks} ranks x {parts} parts ({make}) k={k} keys")
+                assert_same(gc[order], oc, f"multi unordered {n_ranks} ranks x {parts} parts ({make}) k={k} counts")
+                # the digest over all parts, and windows of the read order that straddle part boundaries
+                t = [0, 0, 0, 0]
+                for h in hs:
+                    assert 1 <= h.n_parts <= parts
+                    t = [(a + b) & ((1 << 64) - 1) for a, b in zip(t, h.summary())]
+                assert tuple(t) == orc.hist_summary(ok, oc)
+                h0 = max(hs, key=lambda h: h.n_parts)
+                if h0.distinct > 10:
+                    fk, fc = h0.download()
+                    a, b = h0.distinct // 3, h0.distinct - h0.distinct // 4
+                    wk, wc = h0.download(a, b - a)
+                    assert_same(wk, fk[a:b], "window of a histogram of several parts: keys")
+                    assert_same(wc, fc[a:b], "window of a histogram of several parts: counts")
+                if k >= 23:
+                    lt = m.last_times()
+                    assert lt["parts"] == parts and lt["total_ms"] > 0
+                    assert (lt["bytes_moved"] > 0) == (n_ranks > 1)
                 for h in hs:
                     h.free()
             m.dna_free(d)
+
+
+def test_bench_gpus2_one_process_rehearsal():
+    """`python bench.py --gpus 2` started the way the driver starts it (a plain command, no torchrun): on a one-GPU box
+    the two ranks share device 0 (copy transport, "rehearsal": true); the line keeps the contract's fields."""
+    import json
+    import subprocess
+    import sys
+    from __graft_entry__ import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n-bases", "200000000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["launcher"] == "one-process" and line["unit"] == "k-mers/s"
+    assert line["config"]["distinct"] > 0 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["roofline"] and line["exchange"]["parts"] >= 1
+    pkg = load_package()
+    if pkg.device_count() < 2:
+        assert line["rehearsal"] is True and line["transport"] == "copy" and line["devices"] == [0, 0]
 
 
 def test_count_multi_rccl_one_rank(pkg, ctx):
@@ -1042,6 +1084,15 @@ def test_count_multi_rccl_one_rank(pkg, ctx):
 
 # ------------------------------------------------------------------ BASELINE.json sizes (properties)
 
+def oracle_digest(name):
+    """(total, distinct, unique, checksum) of a BASELINE.json config at its FULL size as the CPU oracle counted it in the
+    build container (tools/make_digests.py -> tests/golden/config_digests.json)."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_digests.json")) as f:
+        e = json.load(f)[name]
+    return e["total"], e["distinct"], e["unique"], e["checksum"]
+
+
 def test_config2_k21_100M_against_oracle_summary(ctx):
     """configs[1]: k=21 over 100 Mbase synthetic, seed 0xD2A0001: full histogram digest vs oracle."""
     n, k, seed = 100_000_000, 21, 0xD2A0001
@@ -1049,6 +1100,10 @@ def test_config2_k21_100M_against_oracle_summary(ctx):
     h = ctx.count_kmers(d, k)
     total, distinct, unique, checksum = h.summary()
     assert total == n - k + 1
+    assert (total, distinct, unique, checksum) == oracle_digest("2")
+    hu = ctx.count_kmers_unordered(d, k)          # what bench.py --config 2 runs
+    assert hu.summary() == oracle_digest("2")
+    hu.free()
     words = orc.synth_words(seed, n)
     ok, oc = orc.count_kmers(words, n, k)
     assert (total, distinct, unique, checksum) == orc.hist_summary(ok, oc)
@@ -1084,6 +1139,12 @@ def test_config3_k31_chr1_scale_properties(ctx):
     h = ctx.count_kmers(d, k)
     total, distinct, unique, checksum = h.summary()
     assert total == n - k + 1
+    # total / distinct / unique (test.sql:107-119) and the checksum over all groups: the ORACLE's, counted at this size
+    assert (total, distinct, unique, checksum) == oracle_digest("3"), "ordered engine vs the oracle's digest"
+    hu = ctx.count_kmers_unordered(d, k)          # what bench.py --config 3 runs (super-k-mer engine at this size)
+    assert not hu.is_sorted
+    assert hu.summary() == oracle_digest("3"), "unordered engine vs the oracle's digest"
+    hu.free()
     gk, gc = h.download()
     assert np.all(gk[1:] > gk[:-1]), "keys not strictly ascending"
     assert int(gc.sum()) == total and int((gc == 1).sum()) == unique
@@ -1112,6 +1173,9 @@ def test_config4_k31_3G_properties(ctx, pkg):
     total, distinct, unique, checksum = h.summary()
     assert total == n - k + 1
     assert total - 100 < distinct <= total and unique <= distinct
+    # the ORACLE's digest of the same 3 Gbase (30 key-space slices on the CPU, tools/make_digests.py): both engines and
+    # both multi-GPU exchanges below are compared with it, not with each other
+    assert (total, distinct, unique, checksum) == oracle_digest("4"), "ordered engine vs the oracle's digest"
     prev_last = None
     for first in (0, distinct // 3, distinct - 4_000_000):
         gk, gc = h.download(first, 4_000_000)
@@ -1138,7 +1202,7 @@ def test_config4_k31_3G_properties(ctx, pkg):
     # the unordered entry point (super-k-mer engine: the bench's default workload): the same groups, i.e. the same digest
     hu = ctx.count_kmers_unordered(d, k)
     assert not hu.is_sorted, "3 Gbase k=31 is expected to go through the super-k-mer engine"
-    assert hu.summary() == (total, distinct, unique, checksum)
+    assert hu.summary() == oracle_digest("4"), "unordered engine vs the oracle's digest"
     hu.free()
     d.free()
     ctx.trim()
@@ -1163,5 +1227,5 @@ def test_config4_k31_3G_properties(ctx, pkg):
         ho.free()
     for r in recs:
         r.free()
-    assert (t_sum, d_sum, u_sum, c_sum) == (total, distinct, unique, checksum)
+    assert (t_sum, d_sum, u_sum, c_sum) == oracle_digest("4")
     ctx.trim()
