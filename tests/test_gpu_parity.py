@@ -1036,7 +1036,8 @@ def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
                 if k >= 23:
                     lt = m.last_times()
                     assert lt["parts"] == parts and lt["total_ms"] > 0
-                    assert (lt["bytes_moved"] > 0) == (n_ranks > 1)
+                    if count is None:           # (a window may lie in one rank's chunk: then nothing travels)
+                        assert (lt["bytes_moved"] > 0) == (n_ranks > 1)
                 for h in hs:
                     h.free()
             m.dna_free(d)
