@@ -30,10 +30,11 @@
 
 namespace dnagpu {
 
-constexpr int SK_NT = 256;                       // threads of a front-end workgroup
-constexpr int SK_TILE_ROWS = (SK_NT - 1) * 32;   // rows (k-mers) a tile emits records for: the last thread only supplies hashes
+constexpr int SK_NT = 256;                       // threads of a front-end workgroup: four waves, each working tile after tile on its own
+constexpr int SKW_ROWS = 63 * 32;                // rows (k-mers) a WAVE tile emits records for: lane 63 only supplies hashes
+constexpr int SK_TILE_ROWS = (SK_NT / 64) * SKW_ROWS;   // one round of the workgroup's waves (chunks are cut at multiples of it)
 constexpr int SK_MAX_C0 = 128;                   // most coarse buckets (digits of level 0): 2^32 rows need 80
-constexpr int SK_LIST = 2048;                    // records of a tile listed in LDS (a tile of random bases has ~900)
+constexpr int SKW_LIST = 512;                    // records of a wave tile listed in LDS (a tile of random bases has ~225)
 
 int sk_tile_rows() { return SK_TILE_ROWS; }
 int sk_max_c0() { return SK_MAX_C0; }
@@ -41,27 +42,31 @@ int sk_count_cap() { return 4096; }              // distinct keys of a bucket <=
 
 typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
 
-// bijective 32-bit mix of the 30-bit m-mer value: distinct m-mers never tie
+// bijective 32-bit mix of the 30-bit m-mer value: distinct m-mers never tie.  Four operations (the sweeps of level 0 are
+// bound by VALU instruction issue: 36 per row in round 2, 9 of them this hash): on random sequence the order it gives
+// makes runs as long as the seven-operation mix it replaces (8.99 k-mers per record at k = 31; tools/hash_eval.py).
 __device__ __forceinline__ u32 sk_mix(u32 h)
 {
-    h += h << 10;
-    h ^= h >> 6;
-    h += h << 3;
-    h ^= h >> 11;
-    h += h << 15;                                 // (a last h ^= h >> 16 would only touch the low half: the order of two
-    return h;                                     // hashes is decided there once in 65,536 pairs; sk_digits re-mixes anyway)
+    h += h << 11;                                 // (two shift-adds in a row would be fused into one quarter-rate multiply)
+    h ^= h >> 7;
+    h += h << 17;
+    return h;
 }
 
-// the three bucket digits of a minimizer hash.  The minimum of w hashes is small, i.e. its high bits are
-// biased; a multiplication by an odd constant spreads any smooth density evenly over the product's top bits.
+// the three bucket digits of a minimizer hash.  The minimum of w hashes is small, i.e. its high bits are biased: the
+// digits are cut from a product of the hash's LOW 24 bits (unbiased) with an odd constant -- v_mul_u32_u24 is a
+// full-rate instruction, the 32-bit multiply this replaces a quarter-rate one.  d2 and d1 come from product bits 2..15
+// (functions of the hash's low 16 bits), d0 from bits 16..31 scaled to [0, c0) by a second 24-bit multiply.
 struct SkDigits {
     u32 d0, d1, d2;
 };
+__device__ __forceinline__ u32 sk_digit_word(u32 hmin) { return __umul24(hmin, 0x9E3779u); }
+__device__ __forceinline__ u32 sk_digit0(u32 g, u32 c0) { return __umul24(g >> 16, c0) >> 16; }
 __device__ __forceinline__ SkDigits sk_digits(u32 hmin, u32 c0, u32 b1mask)
 {
-    const u32 g = hmin * 0x9E3779B1u;
+    const u32 g = sk_digit_word(hmin);
     SkDigits r;
-    r.d0 = ((g >> 16) * c0) >> 16;
+    r.d0 = sk_digit0(g, c0);
     r.d1 = (g >> 6) & b1mask;
     r.d2 = (g >> 2) & 15u;
     return r;
@@ -86,108 +91,146 @@ __device__ __forceinline__ u32 wave_incl_max(u32 x)
     return (u32)v;
 }
 
+// LDS written by one lane and read by another of the same wave: DS operations of a wave execute in program
+// order, so only the compiler has to be kept from reordering them
+__device__ __forceinline__ void sk_wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lane i <- lane i + 1 (lane 63 <- 0) / lane i <- lane i - 1 (lane 0 <- 0): one VALU operation each
+__device__ __forceinline__ u32 wave_next(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+__device__ __forceinline__ u32 wave_prev(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+
 // ------------------------------------------------------------------------------------------------
-// Front end of both dna sweeps: one tile = rows [row0, row0 + n_rows), n_rows <= SK_TILE_ROWS, thread t owns
-// the 32 rows row0 + 32 t ...  Every thread ends with the window-minimum hash of each of its rows in hm[]
-// and the state of the record that is open at its first row (`c0` = rows of that record before it).  Records are
-// cut at tile boundaries (one extra record per 8160 rows).
+// Front end of both dna sweeps, ONE WAVE per tile and nothing shared between waves: a tile = rows [row0, row0 + n_rows),
+// n_rows <= SKW_ROWS; lane l owns the 32 rows row0 + 32 l ... (lane 63 owns none: it supplies the hashes that complete
+// lane 62's windows).  What a lane needs of its neighbours -- the next lane's first W-1 hashes, the boundary minima, the
+// last run break before its rows -- moves by DPP wave shifts and a DPP scan: no LDS, no barrier (round 2's workgroup
+// tile exchanged them through LDS behind five workgroup barriers; the two sweeps together took 7.9 ms at 3 Gbase).
+// Every lane ends with the window-minimum hash of each of its rows in hm[]; sk_front_open adds the state of the record
+// that is open at its first row.  Records are cut at tile boundaries (one extra record per 2016 rows: +0.4 %).
 template <int W>
 struct SkFront {
     u32 hm[32];
-    u32 next_first;        // hm[0] of the next thread (undefined for the tile's last row owner: forced end there)
-    u32 c0;                // length so far of the record open at this thread's first row
-    u32 n_valid;           // rows of this thread that exist (0..32)
+    u32 next_first;        // hm[0] of the next lane (lane 63: 0)
+    u32 prev_last;         // hm[31] of the lane before (lane 0: 0)
+    u32 n_valid;           // rows of this lane that exist (0..32)
     u32 n_rows;            // rows of the tile
+    bool plain;            // wave-uniform: a full tile whose records are its natural runs (see sk_front)
+    // sk_front_open:
+    u32 ns0;               // start row of the natural run that is open at this lane's first row
+    u32 c0;                // length so far of the record open at this lane's first row
 };
 
 template <int W>
 __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 n_rows,
-                                         u32 lmax, u32 *hs /* [(W-1) * SK_NT] */, u32 *hx /* [2 * SK_NT + 8] */,
-                                         u64 *wsh /* [SK_NT + 2] or null: the tile's words, word 0 = the one holding pos0 */)
+                                         u32 lmax, u64 *wsh /* this wave's [66] or null: the tile's words, word 0 = the one holding pos0 */)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the 64 bases from this thread's first row on (pos0 + 32 t): 4 dwords
-    const u64 pos = pos0 + (u64)tid * 32;
+    const int lane = threadIdx.x & 63;
+    // the 64 bases from this lane's first row on (pos0 + 32 lane): 4 dwords
+    const u64 pos = pos0 + (u64)lane * 32;
     const u64 w = pos >> 5;
-    const unsigned sh = (unsigned)(pos & 31) * 2;          // workgroup-uniform
+    const unsigned sh = (unsigned)(pos & 31) * 2;          // wave-uniform
     const u64 w0 = w < n_words ? words[w] : 0, w1 = w + 1 < n_words ? words[w + 1] : 0;
     u64 lo = w0, hi = w1;
     u64 w2 = 0;
-    if (sh || (wsh && tid == SK_NT - 1)) {
+    if (sh || (wsh && lane == 63)) {
         w2 = w + 2 < n_words ? words[w + 2] : 0;
         if (sh) {
             lo = (w0 >> sh) | (w1 << (64 - sh));
             hi = (w1 >> sh) | (w2 << (64 - sh));
         }
     }
-    if (wsh) {                                             // (the previous tile's readers are behind this tile's barriers... see below)
-        wsh[tid] = w0;
-        if (tid == SK_NT - 1) {
-            wsh[SK_NT] = w1;
-            wsh[SK_NT + 1] = w2;
+    if (wsh) {                                             // (the previous tile's payload reads are this wave's own, earlier in program order)
+        wsh[lane] = w0;
+        if (lane == 63) {
+            wsh[64] = w1;
+            wsh[65] = w2;
         }
     }
     const u32 d[4] = {(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
-    u32 a[32 + W - 1];
+    constexpr int B = W - 1;                               // a window = W hashes = a[i .. i + B]
+    constexpr int N = 32 + B;
+    static_assert(W >= 9 && W <= 18, "window lengths of k = 23 .. 32 at m = 15");
+    u32 a[N];
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const int q = (2 * j) >> 5, s = (2 * j) & 31;
         const u32 v = __builtin_amdgcn_alignbit(d[q + 1], d[q], s) & 0x3FFFFFFFu;   // 15 bases
         a[j] = sk_mix(v);
     }
-    // the next thread's first W-1 hashes complete this thread's windows
+    // the next lane's first W-1 hashes complete this lane's windows
 #pragma unroll
-    for (int j = 0; j < W - 1; j++)
-        hs[j * SK_NT + tid] = a[j];
-    __syncthreads();
+    for (int j = 0; j < B; j++)
+        a[32 + j] = wave_next(a[j]);
+    // Window minima in three operations per row whatever W (van Herk / Gil-Werman): cut a[] into blocks of B; with
+    // suf[i] = min of a[i .. end of i's block] and pre[i] = min of a[start of i's block .. i], the window [i, i + B]
+    // is suf[i] and pre[i + B] together (i + B sits in the next block at i's offset).  (Round 2 took the minima by
+    // doubling: 4 x 47 + 32 operations for 32 rows; this is 2 x 30 + 32.)
+    u32 suf[N], pre[N];
 #pragma unroll
-    for (int j = 0; j < W - 1; j++)
-        a[32 + j] = tid + 1 < SK_NT ? hs[j * SK_NT + tid + 1] : 0u;
-    // window minima by doubling: after steps 1, 2, 4, ... a[i] = min over [i, i + P), P = largest power of two <= W
-    constexpr int P = W >= 16 ? 16 : 8;
-    static_assert(W >= 9 && W <= 18, "window lengths of k = 23 .. 32 at m = 15");
+    for (int i = N - 1; i >= 0; i--)
+        suf[i] = (i == N - 1 || (i + 1) % B == 0) ? a[i] : min(a[i], suf[i + 1]);
 #pragma unroll
-    for (int s = 1; s < P; s *= 2)
-#pragma unroll
-        for (int i = 0; i + s < 32 + W - 1; i++)
-            a[i] = min(a[i], a[i + s]);
+    for (int i = 0; i < N; i++)
+        pre[i] = (i % B == 0) ? a[i] : min(a[i], pre[i - 1]);
 #pragma unroll
     for (int j = 0; j < 32; j++)
-        f.hm[j] = min(a[j], a[j + W - P]);
+        f.hm[j] = min(suf[j], pre[j + B]);
 
-    const u32 r0 = (u32)tid * 32;
+    const u32 r0 = (u32)lane * 32;
     f.n_valid = r0 >= n_rows ? 0u : (n_rows - r0 < 32u ? n_rows - r0 : 32u);
     f.n_rows = n_rows;
     // neighbours' boundary minima
-    hx[tid] = f.hm[0];
-    hx[SK_NT + tid] = f.hm[31];
-    __syncthreads();
-    f.next_first = tid + 1 < SK_NT ? hx[tid + 1] : 0u;
-    const u32 prev_last = tid > 0 ? hx[SK_NT + tid - 1] : 0u;
-    // last natural break (a row whose minimum differs from the row before; the tile's first row counts) among this
-    // thread's rows, as row index + 1 (0 = none) -> the run that is open at the next thread's first row
+    f.next_first = wave_next(f.hm[0]);
+    f.prev_last = wave_prev(f.hm[31]);
+    // A PLAIN tile: full, and no run of equal minima longer than a record holds, so that its records are exactly its
+    // natural runs (cut at the tile's end).  On random sequence a run is at most W <= 18 rows (an m-mer occurrence stays
+    // the minimum of at most W windows); longer runs need a repeated m-mer (low-complexity sequence).  Test on every
+    // fourth row of the tile: six such samples in a row span 21 rows -- more than any run of W rows covers, and any run
+    // of more than lmax >= 23 rows covers six of them -- so six equal samples in a row send the tile through the
+    // general walk, and nothing else does.
+    u32 smp[13];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        smp[i] = f.hm[4 * i];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+        smp[8 + i] = i == 0 ? f.next_first : wave_next(f.hm[4 * i]);
+    bool long_run = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        long_run = long_run || (smp[i] == smp[i + 1] && smp[i + 1] == smp[i + 2] && smp[i + 2] == smp[i + 3] &&
+                                smp[i + 3] == smp[i + 4] && smp[i + 4] == smp[i + 5]);
+    f.plain = n_rows == (u32)SKW_ROWS && __ballot(long_run && lane < 63) == 0;
+}
+
+// what the general walk (sk_records / sk_records_all) and the start rows of a plain tile's records need of the lanes
+// before this one: the last natural break (a row whose minimum differs from the row before; the tile's first row counts)
+// among the lanes' rows -> ns0 = the start row of the natural run that reaches this lane's first row from the left, and
+// c0 = the length so far of the RECORD open there (records are cut every lmax rows of a run)
+template <int W>
+__device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
+{
+    const int lane = threadIdx.x & 63;
+    const u32 r0 = (u32)lane * 32;
     u32 lb = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
-        const bool brk = j == 0 ? (tid == 0 || f.hm[0] != prev_last) : (f.hm[j] != f.hm[j - 1]);
+        const bool brk = j == 0 ? (lane == 0 || f.hm[0] != f.prev_last) : (f.hm[j] != f.hm[j - 1]);
         if (brk)
             lb = r0 + (u32)j + 1u;
     }
-    const u32 inc = wave_incl_max(lb);
-    __syncthreads();                                       // hx is reused for the wave maxima
-    if (lane == 63)
-        hx[2 * SK_NT + wave] = inc;
-    __syncthreads();
-    u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xf, 0xf, false);   // wave_shr:1: the lanes before this one
-    if (lane == 0)
-        before = 0;
-    for (int q = 0; q < wave; q++)
-        before = max(before, hx[2 * SK_NT + q]);
-    // `before` >= 1 for every thread but thread 0 (row 0 is a break); thread 0's own row 0 is a break too
-    const u32 ns0 = before ? before - 1u : 0u;             // start row of the natural run that reaches r0 from the left
-    const bool first_break = tid == 0 || f.hm[0] != prev_last;
-    f.c0 = first_break ? 0u : (r0 - ns0) % lmax;
-    __syncthreads();                                       // hs / hx may be rewritten by the caller
+    const u32 before = wave_prev(wave_incl_max(lb));       // over the lanes before this one (lane 0: 0)
+    // `before` >= 1 for every lane but lane 0 (row 0 is a break); lane 0's own row 0 is a break too
+    f.ns0 = before ? before - 1u : 0u;
+    const bool first_break = lane == 0 || f.hm[0] != f.prev_last;
+    f.c0 = first_break ? 0u : (r0 - f.ns0) % lmax;
+    if (first_break)
+        f.ns0 = r0;
 }
 
 // the same walk with the callback at EVERY row position (end = a record ends at this thread's row j; false for rows
@@ -195,7 +238,7 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
 template <int W, typename Emit>
 __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
-    const u32 r0 = (u32)threadIdx.x * 32;
+    const u32 r0 = (u32)(threadIdx.x & 63) * 32;
     u32 c = f.c0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -216,7 +259,7 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Em
 template <int W, typename Emit>
 __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
-    const u32 r0 = (u32)threadIdx.x * 32;
+    const u32 r0 = (u32)(threadIdx.x & 63) * 32;
     u32 c = f.c0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -237,28 +280,43 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &
 }
 
 // ------------------------------------------------------------------------------------------------
-// sk_hist0: records per coarse digit of every chunk of rows (the histogram the generic prefix kernels take)
+// sk_hist0: records per coarse digit of every chunk of rows (the histogram the generic prefix kernels take).  The
+// chunk's wave tiles go round the workgroup's four waves; the waves meet only at the histogram (LDS adds).
 template <int W>
-__global__ __launch_bounds__(SK_NT) void sk_hist0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
+__global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                          const u64 *__restrict__ words, u64 n_words, u64 first,
                                                          u32 lmax, u32 c0n, u32 b1mask, u32 r0n /* digits of the root's split */,
                                                          u32 *__restrict__ hist)
 {
-    __shared__ u32 hs[(W - 1) * SK_NT];
-    __shared__ u32 hx[2 * SK_NT + 8];
-    __shared__ u32 h[SK_MAX_C0];
+    __shared__ u32 h[SK_MAX_C0 + 64];             // (+ a word per lane for the adds that count nothing)
     if (blockIdx.x >= n_chunks)
         return;
     const Chunk ch = chunks[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (u32 d = threadIdx.x; d < r0n; d += SK_NT)
         h[d] = 0;
     __syncthreads();
-    for (u32 t0 = 0; t0 < ch.len; t0 += SK_TILE_ROWS) {
-        const u32 n_rows = ch.len - t0 < (u32)SK_TILE_ROWS ? ch.len - t0 : (u32)SK_TILE_ROWS;
+    for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
+        const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, hs, hx, nullptr);
-        if (threadIdx.x < SK_NT - 1)
-            sk_records<W>(f, lmax, [&](int, u32, u32, u32 hmin) { atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u); });
+        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, nullptr);
+        if (f.plain) {
+            // a record ends at every row whose successor has another minimum (lane 62's last row: the tile's end).  No
+            // branch per row: a lane whose row ends nothing adds to a word of its own behind the histogram.
+            if (lane < 63) {
+                const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
+                    const u32 d0 = sk_digit0(sk_digit_word(f.hm[j]), c0n);
+                    atomicAdd(&h[nxt != f.hm[j] ? d0 : (u32)SK_MAX_C0 + (u32)lane], 1u);
+                }
+            }
+        } else {
+            sk_front_open<W>(f, lmax);
+            if (lane < 63)
+                sk_records<W>(f, lmax, [&](int, u32, u32, u32 hmin) { atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u); });
+        }
     }
     __syncthreads();
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;
@@ -278,84 +336,81 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                                                             const u32 *__restrict__ hist, const u32 *__restrict__ tot,
                                                             ull2_t *__restrict__ recs, int dbg)
 {
-    __shared__ u32 hs[(W - 1) * SK_NT];
-    __shared__ u32 hx[2 * SK_NT + 8];
-    __shared__ u32 gpos[SK_MAX_C0];               // where the chunk's next record of each digit goes
-    __shared__ u64 wsh[SK_NT + 2];                // the tile's packed words: record payloads are cut from here
-    __shared__ u64 list[SK_LIST];                 // hmin << 32 | start row << 5 | (len-1)
-    __shared__ u32 wtot[SK_NT / 64];
+    __shared__ u32 gpos[SK_MAX_C0];               // where the chunk's next record of each digit goes (all waves: LDS adds)
+    __shared__ u64 wsh_all[SK_NT / 64][66];       // per wave: the tile's packed words -- record payloads are cut from here
+    __shared__ u64 list_all[SK_NT / 64][SKW_LIST + 64];   // per wave: hmin << 32 | start row << 5 | (len-1); + an entry per lane for writes that list nothing
     if (blockIdx.x >= n_chunks)
         return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const Chunk ch = chunks[blockIdx.x];
     const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
     const u32 *trow = tot;                         // the root is node 0: its totals row is row 0
     for (u32 d = tid; d < r0n; d += SK_NT)
         gpos[d] = trow[d] + hrow[d];
     __syncthreads();
-    for (u32 t0 = 0; t0 < ch.len; t0 += SK_TILE_ROWS) {
-        const u32 n_rows = ch.len - t0 < (u32)SK_TILE_ROWS ? ch.len - t0 : (u32)SK_TILE_ROWS;
+    u64 *wsh = wsh_all[wave], *wl = list_all[wave];
+    const u64 below = ((u64)1 << lane) - 1;
+    for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
+        const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         const u64 tile_pos = first + ch.off + t0;
         const u32 fo = (u32)(tile_pos & 31);
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, hs, hx, wsh);
-        // The records that end in this tile (usually ~900) are listed in LDS, every wave in its own quarter of the list
-        // (ballot + prefix count per row position: no atomics), and every thread then builds the payloads of its share
-        // -- building them where they end would run the payload code for all 32 row positions of every wave, ~9 times
-        // the work.  A wave that would overflow its quarter (a tile of very short runs: low-complexity sequence) has the
-        // tile redone in four passes of eight row positions each, which always fit.
-        constexpr u32 WCAP = SK_LIST / (SK_NT / 64);
+        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, wsh);
+        // The records that end in this tile (usually ~225) are listed in the wave's LDS list (ballot + prefix count per
+        // row position: no atomics), and every lane then builds the payloads of its share -- building them where they end
+        // would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the list
+        // (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
+        // fit (8 x 63 records).
         int n_pass = 1;
+        bool plain = f.plain;
+        sk_front_open<W>(f, lmax);
         for (int pass = 0; pass < n_pass; pass++) {
             const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
-            u32 wrun = 0;                          // wave-uniform: records this wave has listed
-            {
-                u64 *wl = list + (u32)(tid >> 6) * WCAP;
-                const u64 below = ((u64)1 << (tid & 63)) - 1;
-                sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
-                    const bool end = end_any && j >= jlo && j < jhi;
-                    const u64 b = __ballot(end);
-                    if (end) {
-                        const u32 pos = wrun + (u32)__popcll(b & below);
-                        if (pos < WCAP)
-                            wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 5) | (u64)(len - 1);
-                    }
-                    wrun += (u32)__popcll(b);
-                });
-            }
-            if ((tid & 63) == 0)
-                wtot[tid >> 6] = wrun;
-            __syncthreads();
-            u32 tile_recs = 0, wmax = 0;
-            u32 wbase[SK_NT / 64 + 1];
+            u32 wrun = 0;                          // wave-uniform: records listed
+            if (plain) {
+                // records = natural runs: no branch per row -- a lane whose row ends nothing (and lane 63, which owns no
+                // rows) writes to an entry of its own behind the list; so does whatever would overflow the list (the tile
+                // is then redone in four passes by the general walk)
+                const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
+                const u32 dummy = (u32)SKW_LIST + (u32)lane;
+                u32 start = f.ns0;
 #pragma unroll
-            for (int q = 0; q < SK_NT / 64; q++) {
-                wbase[q] = tile_recs;
-                tile_recs += wtot[q];
-                wmax = max(wmax, wtot[q]);
-            }
-            wbase[SK_NT / 64] = tile_recs;
-            if (wmax > WCAP) {                     // (only possible in the single pass: eight rows x 64 lanes = WCAP)
+                for (int j = 0; j < 32; j++) {
+                    const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
+                    const u32 row = (u32)lane * 32 + (u32)j;
+                    const bool end = nxt != f.hm[j] && lane < 63;
+                    const u64 b = __ballot(end);
+                    const u32 pos = wrun + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+                    wl[end ? min(pos, (u32)SKW_LIST + 63u) : dummy] = ((u64)f.hm[j] << 32) | (u64)((start << 5) | (row - start));
+                    start = end ? row + 1 : start;
+                    wrun += (u32)__popcll(b);
+                }
+                plain = false;                     // (if the list overflowed: the general walk below)
+            } else
+            sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
+                const bool end = end_any && j >= jlo && j < jhi;
+                const u64 b = __ballot(end);
+                if (end) {
+                    const u32 pos = wrun + (u32)__popcll(b & below);
+                    if (pos < (u32)SKW_LIST)
+                        wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 5) | (u64)(len - 1);
+                }
+                wrun += (u32)__popcll(b);
+            });
+            if (wrun > (u32)SKW_LIST) {            // (only possible in the single pass)
                 n_pass = 4;
                 pass = -1;
-                __syncthreads();
+                sk_wave_fence();
                 continue;
             }
+            sk_wave_fence();                       // list and words written by other lanes of this wave
             if (!SK_DBG(2))
-                for (u32 e = tid; e < tile_recs; e += SK_NT) {
-                    u32 wq = 0;
-#pragma unroll
-                    for (int q = 1; q < SK_NT / 64; q++)
-                        wq += e >= wbase[q] ? 1u : 0u;
-                    u32 eb = 0;
-#pragma unroll
-                    for (int q = 1; q < SK_NT / 64; q++)
-                        eb = wq == (u32)q ? wbase[q] : eb;
-                    const u64 en = list[wq * WCAP + (e - eb)];
+                for (u32 e = (u32)lane; e < wrun; e += 64) {
+                    const u64 en = wl[e];
                     const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
                     const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
                     const u32 len = ((u32)en & 31u) + 1u;
-                    const u32 q = ((u32)(en >> 5) & 0x1FFFu) + fo; // first base of the run, relative to the tile's first word
+                    const u32 q = ((u32)(en >> 5) & 0x7FFu) + fo;  // first base of the run, relative to the tile's first word
                     const u32 wi = q >> 5, sh = (q & 31u) * 2u;
                     const u64 a0 = wsh[wi], a1 = wsh[wi + 1], a2 = wsh[wi + 2];
                     u64 lo = funnel(a0, a1, sh), hi = funnel(a1, a2, sh);
@@ -375,7 +430,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     else if (r.x == 0x1234567 && r.y == 0x89)
                         recs[0] = r;
                 }
-            __syncthreads();                       // wsh / list are rewritten by the next pass / tile
+            sk_wave_fence();                       // wsh / list are rewritten by the next pass / tile
         }
     }
 }
@@ -482,15 +537,6 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
         }
         __syncthreads();
     }
-}
-
-// LDS written by one lane and read by another of the same wave: DS operations of a wave execute in program
-// order, so only the compiler has to be kept from reordering them
-__device__ __forceinline__ void sk_wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // exclusive scan over lanes 0..15 (one DPP row); lanes >= 16 get garbage
