@@ -48,7 +48,9 @@ class _MultiTimes(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdnagpu.so")
+    # DNAGPU_LIB_PATH: A/B runs of two builds on one box (tools/ab.sh); this wrapper is test / bench tooling, the
+    # library itself reads no environment variable
+    return os.environ.get("DNAGPU_LIB_PATH") or os.path.join(_HERE, "libdnagpu.so")
 
 
 def lib():

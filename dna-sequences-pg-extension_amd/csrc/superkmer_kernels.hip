@@ -969,7 +969,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     // An insert that meets its own fingerprint re-derives the claimant's key from the staged records (owner table ->
     // record -> shift) and compares in full: equal = a copy, counted at the claimant's id; different = a fingerprint
     // collision (one comparison in 2^20), which just probes on.  No key value is reserved.
-    __shared__ __attribute__((aligned(16))) u32 tab[SKC_SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 tab[SKC_SLOTS + 64];   // (+ a word per lane that is never free: see the probe loops)
     __shared__ __attribute__((aligned(16))) u32 cop2[SKC_NT * SKC_KPT / 2];    // copies per claimant id, 16-bit halves
     unsigned short *cop16 = reinterpret_cast<unsigned short *>(cop2);
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
@@ -982,12 +982,13 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         return;
     for (int q = tid; q < SKC_SLOTS; q += SKC_NT)
         tab[q] = SKC_FREE;
+    if (tid < 64)
+        tab[SKC_SLOTS + tid] = 0;
     for (int q = tid; q < SKC_NT * SKC_KPT / 2; q += SKC_NT)
         cop2[q] = 0;
     if (tid < 2)
         copy_seen[tid] = 0;
     const u64 kmask = kmer_mask(k);
-    const u64 below = ((u64)1 << lane) - 1;
     u32 li = list[lq];
     u32 off = list_off[lq];                        // the bucket's output range is [off, off + its k-mers): the exclusive scan of
     Node nd = fin[li];                             // the buckets' k-mer counts, so no cursor is involved
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     // What a thread keeps of a bucket until its output range has arrived: the keys of its quad whose slots it claimed,
     // their counts, its wave's offset.
     constexpr int KEEP = SKC_KPT;
-    u64 pk[KEEP];
+    u32 pkl[KEEP], pkh[KEEP];
     u32 pc[KEEP];
     u32 p_mask = 0, p_before = 0, p_groups = 0, p_li = 0, p_off = 0, p_kmers = 0;
     bool have_prev = false, p_copy = false;
@@ -1008,23 +1009,25 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
 
     auto emit_prev = [&]() {
         // every wave's claimed keys go out position by position: lanes that claimed their q-th key write one
-        // contiguous run per store instruction
+        // contiguous run per store instruction (wave-uniform base pointers, 32-bit offsets)
         const u64 obase = p_off;
+        u64 *ok = out_keys + obase;
+        u32 *oc = out_counts + obase;
         u32 run = p_before;
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
             const bool mine = (p_mask >> q) & 1u;
             const u64 b = __ballot(mine);
             if (mine && !SK_DBG(64)) {
-                const u64 o = obase + run + (u32)__popcll(b & below);
-                out_keys[o] = pk[q];
-                out_counts[o] = pc[q];
+                const u32 o = run + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+                ok[o] = ((u64)pkh[q] << 32) | pkl[q];
+                oc[o] = pc[q];
             }
             run += (u32)__popcll(b);
         }
         if (p_copy)                                // a bucket that held copies: the rest of its range is count-0 padding
             for (u32 i = p_groups + (u32)tid; i < p_kmers; i += SKC_NT)
-                out_counts[obase + i] = 0;
+                oc[i] = 0;
         if (tid == 0) {
             seg_off[p_li] = obase;
             seg_cnt[p_li] = p_groups;
@@ -1069,57 +1072,69 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u32 off2 = has_next2 ? list_off[lq2] : off_next;
         const Node nn2 = fin[ln2];
         __syncthreads();                           // A2: lrec[] and ownq[] complete, every slot of the previous bucket reset
-        // ---- this thread's quad
-        u64 ck[KEEP];
-        u32 cslot[KEEP];
+        // ---- this thread's quad.  32-bit arithmetic throughout (the kernel is bound by VALU issue: 343 vector
+        // instructions per wave and bucket in round 2's form, 74 % of the SIMDs' issue slots): the quad's k-mers are cut
+        // from a three-dword window of the record that moves on two bits per k-mer (three v_alignbit), slot and
+        // fingerprint come from one 32-bit product (the slot through a full-rate 24-bit multiply), and the probe loop
+        // carries the slot's byte address only -- what a claim leaves behind is assigned once, after the loop.
+        u32 ckl[KEEP], ckh[KEEP];
+        u32 cslot[KEEP];                           // byte address of the claimed slot
         u32 c_mask = 0;
 #pragma unroll
         for (int q = 0; q < SKC_KPT; q++) {
-            ck[q] = 0;
+            ckl[q] = ckh[q] = 0;
             cslot[q] = 0;
         }
         if ((u32)tid < n_quads) {
             const u32 e = ownq[tid];
             const ull2_t rec = lrec[e & 511u];
-            const u32 rl = (u32)((rec.y >> 44) & 31) + 1u;
+            const u32 p0 = (u32)rec.x, p1 = (u32)(rec.x >> 32), p2 = (u32)rec.y, p3h = (u32)(rec.y >> 32);
+            const u32 rl = ((p3h >> 12) & 31u) + 1u;
+            const u32 p3 = p3h & 0xFFFu;
             const u32 j0 = (e >> 9) * SKC_KPT;
-            const u64 hi44 = rec.y & (((u64)1 << 44) - 1);
-            u64 slo = funnel(rec.x, hi44, 2 * j0), shi = hi44 >> (2 * j0);
+            const bool up = j0 >= 16;                            // the quad starts in the record's second dword
+            const u32 sh = (2 * j0) & 31u;
+            const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2, a3 = up ? 0u : p3;
+            u32 w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh),
+                w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
+            const u32 hmask = (u32)(kmask >> 32);                // (k >= 23: the low dword is whole)
+            const u32 id0 = (u32)tid << 2;
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
                 if (j0 + (u32)q < rl) {
-                    const u64 kv = slo & kmask;
-                    slo = (slo >> 2) | (shi << 62);
-                    shi >>= 2;
+                    const u32 kl = w0, kh = w1 & hmask;
+                    w0 = __builtin_amdgcn_alignbit(w1, w0, 2);
+                    w1 = __builtin_amdgcn_alignbit(w2, w1, 2);
+                    w2 >>= 2;
+                    ckl[q] = kl;
+                    ckh[q] = kh;
                     if (SK_DBG(32)) {
-                        c_mask |= (kv & 1) ? 1u << q : 0u;
-                        ck[q] = kv;
+                        c_mask |= (kl & 1) ? 1u << q : 0u;
                     } else {
-                        const u32 x = ((u32)kv ^ (u32)(kv >> 32)) * 0x9E3779B1u;
-                        u32 slot = ((x >> 16) * (u32)SKC_SLOTS) >> 16;
-                        u32 fp = (x ^ (u32)(kv >> 39)) & 0xFFFFFu;
-                        fp = fp == 0xFFFFFu ? 0u : fp;                       // (fp = all ones with id 4095 would read as a free slot)
-                        const u32 word = (fp << 12) | ((u32)tid << 2) | (u32)q;
+                        const u32 x = (kl ^ kh) * 0x9E3779B1u;
+                        u32 sa = ((u32)__umul24(x >> 16, (u32)SKC_SLOTS) >> 16) << 2;        // byte address of the home slot
+                        const u32 y = x ^ (x >> 15);             // (the product's low bits alone depend on the key's low bits only)
+                        // 19 bits of fingerprint under a clear top bit: no word equals the all-ones of a free slot
+                        const u32 word = ((y & 0x7FFFFu) << 12) | id0 | (u32)q;
                         for (;;) {
-                            const u32 old = atomicCAS(&tab[slot], SKC_FREE, word);
+                            const u32 old = atomicCAS(reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + sa), SKC_FREE, word);
                             if (old == SKC_FREE) {
                                 c_mask |= 1u << q;
-                                ck[q] = kv;
-                                cslot[q] = slot;
+                                cslot[q] = sa;
                                 break;
                             }
-                            if ((old >> 12) == fp) {
+                            if ((old ^ word) < 4096u) {
                                 // the claimant's key, from the staged records (its owner entry and record do not change before B)
                                 const u32 oid = old & 0xFFFu;
                                 const u32 oe = ownq[oid >> 2];
                                 const u64 okey = sk_record_kmer(lrec[oe & 511u], (oe >> 9) * SKC_KPT + (oid & 3u), kmask);
-                                if (okey == kv) {  // a copy: counted at the claimant's id
+                                if (okey == (((u64)kh << 32) | kl)) {  // a copy: counted at the claimant's id
                                     atomicAdd(&cop2[oid >> 1], 1u << ((oid & 1u) * 16u));
                                     copy_seen[par] = 1u;
                                     break;
                                 }
                             }
-                            slot = slot + 1 == (u32)SKC_SLOTS ? 0u : slot + 1;
+                            sa = sa + 4 == (u32)SKC_SLOTS * 4u ? 0u : sa + 4;
                         }
                     }
                 }
@@ -1146,11 +1161,12 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const bool any_copy = copy_seen[par] != 0; // (random sequence: no bucket has one, and the copy counters are not read)
 #pragma unroll
         for (int q = 0; q < KEEP; q++) {
-            pk[q] = ck[q];
+            pkl[q] = ckl[q];
+            pkh[q] = ckh[q];
             pc[q] = 0;
             if ((c_mask >> q) & 1u) {
                 pc[q] = 1u;
-                tab[cslot[q]] = SKC_FREE;
+                *reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + cslot[q]) = SKC_FREE;
                 if (any_copy) {
                     const u32 copies = cop16[(u32)tid * SKC_KPT + (u32)q];
                     pc[q] = 1u + copies;
