@@ -1258,6 +1258,10 @@ constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final buc
 constexpr u64 SK_MID_LIMIT = (u64)1 << 27;
 constexpr u32 SK_MID_RECORDS = 1u << 19;           // (a mid bucket is regrouped by one workgroup: 64 tiles, twice)
 constexpr u64 SK_BIG_LIMIT = 0xFFFFFFFFull;
+// Level 1 splits a coarse bucket 512 ways, not 1024: a tile of 8192 records then leaves in runs of 16 records (256
+// bytes) instead of 8 -- sk_scatter1 3.6 - 3.9 instead of 4.9 - 5.2 ms at 3 Gbase (A/B on one box) -- and level 0 takes
+// the bit over (136 coarse buckets at 3 Gbase: its 16-byte stores still combine in L2, 2.2 MB of open lines per XCD).
+constexpr int SK_B1_MAX = 9;
 
 struct SkLevel {                                 // what one forced partition level leaves behind
     Node *next;
@@ -1322,7 +1326,7 @@ static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n, int k)
     const u64 n_final = std::max<u64>(n / leaf_mean, 16);
     const u64 n_mid = (n_final + 15) / 16;
     g.b1 = 1;
-    while (g.b1 < MAX_SPLIT_BITS && ((u64)1 << g.b1) < n_mid)
+    while (g.b1 < SK_B1_MAX && ((u64)1 << g.b1) < n_mid)
         g.b1++;
     g.c0n = (u32)std::min<u64>((n_mid + ((u64)1 << g.b1) - 1) >> g.b1, (u64)sk_max_c0());
     g.r0bits = 1;

@@ -33,7 +33,7 @@ namespace dnagpu {
 constexpr int SK_NT = 256;                       // threads of a front-end workgroup: four waves, each working tile after tile on its own
 constexpr int SKW_ROWS = 63 * 32;                // rows (k-mers) a WAVE tile emits records for: lane 63 only supplies hashes
 constexpr int SK_TILE_ROWS = (SK_NT / 64) * SKW_ROWS;   // one round of the workgroup's waves (chunks are cut at multiples of it)
-constexpr int SK_MAX_C0 = 128;                   // most coarse buckets (digits of level 0): 2^32 rows need 80
+constexpr int SK_MAX_C0 = 256;                   // most coarse buckets (digits of level 0): 2^32 rows need 195
 constexpr int SKW_LIST = 512;                    // records of a wave tile listed in LDS (a tile of random bases has ~225)
 
 int sk_tile_rows() { return SK_TILE_ROWS; }
