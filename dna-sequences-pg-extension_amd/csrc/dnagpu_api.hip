@@ -123,7 +123,42 @@ struct dnagpu_ctx {
     u64 *mailbox;
     unsigned debug_flags;     // DNAGPU_DEBUG_*
 };
-constexpr size_t MAILBOX_BYTES = 65536;
+constexpr size_t MAILBOX_BYTES = (size_t)1 << 20;
+
+// Up to 32 bytes from the host into device memory as a kernel argument: no staging copy, and no wait for a stack
+// variable to be consumed.
+struct Poke32 {
+    u32 w[8];
+};
+__global__ void poke_kernel(u32 *dst, Poke32 v, int n_words)
+{
+    if ((int)threadIdx.x < n_words)
+        dst[threadIdx.x] = v.w[threadIdx.x];
+}
+static hipError_t poke(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    Poke32 v;
+    memset(&v, 0, sizeof v);
+    memcpy(&v, src, bytes <= sizeof v ? bytes : sizeof v);
+    hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(8), 0, st, static_cast<u32 *>(dst), v, (int)((bytes + 3) / 4));
+    return hipGetLastError();
+}
+
+// Small results the host needs between launches (level counters, child lists, totals): copied into the context's pinned
+// mailbox and read from there.  A copy into pageable memory (a stack variable, a std::vector) goes through the
+// runtime's staging path, which costs tens of microseconds per call -- a count makes about ten of them.  Waits for
+// the stream.
+static int read_back(dnagpu_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    if (bytes == 0)
+        return DNAGPU_OK;
+    void *to = bytes <= MAILBOX_BYTES ? static_cast<void *>(ctx->mailbox) : host;
+    HIP_TRY(hipMemcpyAsync(to, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (to != host)
+        memcpy(host, to, bytes);
+    return DNAGPU_OK;
+}
 
 struct dnagpu_dna {
     u64 *words;
@@ -1128,8 +1163,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
     u32 n_nodes = init_nodes ? init_n : 1u, n_big = 0, n_small = 0, n_tiny = 0;
     if (!init_nodes) {
         RC_TRY(ps.alloc(1, &cur));
-        HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));       // root is a stack variable
+        static_assert(sizeof(Node) == 32, "a node travels as one kernel argument");
+        HIP_TRY(poke(cur, &root, sizeof root, st));
     }
     u32 n_nonempty = 1;           // nodes of the current level that uniform data would fill (all, or an owner's share)
 
@@ -1158,8 +1193,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
         HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
         LevelCounters hc;
-        HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        RC_TRY(read_back(ctx, &hc, ctr, sizeof hc));
         if (hc.n_split == 0) {
             n_big = hc.n_big;                    // every node of the final list was planned (and counted) here
             n_small = hc.n_small;
@@ -1198,8 +1232,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         if (src_dna) {
             // the dna root's children say how many keys survive the owner filter
             std::vector<Node> kids(hc.n_next);
-            HIP_TRY(hipMemcpyAsync(kids.data(), next, (size_t)hc.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            RC_TRY(read_back(ctx, kids.data(), next, (size_t)hc.n_next * sizeof(Node)));
             n_keys = 0;
             for (const Node &c : kids)
                 n_keys += c.len;
@@ -1286,8 +1319,7 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
     HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
     HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
     LevelCounters hc;
-    HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    RC_TRY(read_back(ctx, &hc, ctr, sizeof hc));
     lv->n_next = hc.n_next;
     lv->n_chunks = hc.n_chunks;
     RC_TRY(ps.alloc(std::max<u32>(hc.n_chunks, 1), &lv->chunks));
@@ -1352,8 +1384,7 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     root.meta = 32;                              // "remaining bits" of the bucket digits: r0bits + b1 <= 20 of them are split on
     Node *cur = nullptr;
     RC_TRY(ps.alloc(1, &cur));
-    HIP_TRY(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(poke(cur, &root, sizeof root, st));
     const u64 tile = (u64)sk_tile_rows();
     u64 chunk_rows = std::max<u64>(4 * tile, (n + 4095) / 4096);
     chunk_rows = (chunk_rows + tile - 1) / tile * tile;
@@ -1368,8 +1399,7 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     HIP_TRY(launch_level_children(cur, 1, l0.tot, l0.next, nullptr, nullptr, nullptr, 0, st));
     std::vector<Node> &kids = *kids_out;
     kids.resize(l0.n_next);
-    HIP_TRY(hipMemcpyAsync(kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    RC_TRY(read_back(ctx, kids.data(), l0.next, (size_t)l0.n_next * sizeof(Node)));
     u64 n_recs = 0;
     for (const Node &c : kids)
         n_recs += c.len;
@@ -1420,9 +1450,20 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     u32 *d_lens = nullptr;
     RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &d_lens));
     HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
-    HIP_TRY(hipMemcpyAsync(kc.data(), kcount, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(rcn.data(), d_lens, (size_t)l1.n_next * sizeof(u32), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    {
+        const size_t nb = (size_t)l1.n_next * sizeof(u32);
+        if (2 * nb <= MAILBOX_BYTES) {            // both lists through the pinned mailbox, one wait
+            char *mb = reinterpret_cast<char *>(ctx->mailbox);
+            HIP_TRY(hipMemcpyAsync(mb, kcount, nb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(mb + nb, d_lens, nb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            memcpy(kc.data(), mb, nb);
+            memcpy(rcn.data(), mb + nb, nb);
+        } else {
+            HIP_TRY(hipMemcpyAsync(kc.data(), kcount, nb, hipMemcpyDeviceToHost, st));
+            RC_TRY(read_back(ctx, rcn.data(), d_lens, nb));
+        }
+    }
     // heavy: too many k-mers, or too many records for the one workgroup that regroups a mid bucket (its tiles are serial)
     const bool forced = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) != 0;
     auto is_heavy = [&](u32 i) { return kc[i] > mid_limit || (!forced && rcn[i] > SK_MID_RECORDS); };
@@ -1642,8 +1683,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     HIP_TRY(launch_scan_u32(k_range, k_range, n_fin, scan_tmp, totals + 2, st));
     HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 3, st));
     u32 ht[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(ht, totals, sizeof ht, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    RC_TRY(read_back(ctx, ht, totals, sizeof ht));
     const u32 n_small = ht[0], n_big = ht[1];
     const u64 small_keys = ht[2];                // the output slots of the small and big buckets: one per k-mer, in bucket order
     // a big bucket that sk_count_big gives up on is counted again through the expansion: its groups land behind the
@@ -1663,8 +1703,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     RC_TRY(ps.alloc((size_t)out_cap, &oc));
     {
         const u64 init[3] = {small_keys, 0, 0};
-        HIP_TRY(hipMemcpyAsync(cursor, init, sizeof init, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));       // (init is a stack variable)
+        HIP_TRY(poke(cursor, init, sizeof init, st));
     }
     u64 *seg_off = nullptr;
     u32 *seg_cnt = nullptr;
@@ -1690,8 +1729,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
         HIP_TRY(launch_scan_u32(nsl, sfirst, n_big, scan_tmp, totals + 6, st));
         HIP_TRY(launch_scan_u32(mfirst, mfirst, n_big, scan_tmp, totals + 7, st));
         u32 hs[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(hs, totals + 6, sizeof hs, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        RC_TRY(read_back(ctx, hs, totals + 6, sizeof hs));
         const u32 n_slices = hs[0], n_part = hs[1];
         RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &sl_bucket));
         RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &sl_idx));
@@ -1709,8 +1747,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     HIP_TRY(launch_scan_u32(f_over_raw, f_over, n_fin, scan_tmp, totals + 4, st));
     HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 5, st));
     u32 ho[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(ho, totals + 4, sizeof ho, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    RC_TRY(read_back(ctx, ho, totals + 4, sizeof ho));
     const u32 n_over = ho[0];
     const u64 over_keys = ho[1];
     Node *over_nodes = nullptr;
@@ -1748,8 +1785,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
             HIP_TRY(launch_sk_slice_count(bk, nb, sfirst, st));
             HIP_TRY(launch_scan_u32(sfirst, sfirst, nb, stmp, stot, st));
             u32 n_slices = 0;
-            HIP_TRY(hipMemcpyAsync(&n_slices, stot, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            RC_TRY(read_back(ctx, &n_slices, stot, 4));
             u32 *d_r0 = nullptr, *d_nr = nullptr, *d_ko = nullptr, *ktmp = nullptr;
             RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &d_r0));
             RC_TRY(ps.alloc((size_t)std::max<u32>(n_slices, 1), &d_nr));
@@ -1783,8 +1819,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     HIP_TRY(launch_sk_count(fin, list_small, off_small, n_small, recs, k, cursor + 2, seg_off, seg_cnt, ok, oc, st));
     prof_mark(ctx, "end");
     u64 fin_ctr[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(fin_ctr, cursor, 24, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    RC_TRY(read_back(ctx, fin_ctr, cursor, 24));
     const u64 extent = fin_ctr[0];
     const u64 total_groups = fin_ctr[2] + (extent - small_keys);
     if (fin_ctr[1] != 0) {
@@ -1962,9 +1997,10 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
                                   ok, oc, flags, scan_tmp, cls_list, ctx->stream, !sorted);
             prof_mark(ctx, "end");
             if (e == hipSuccess)
-                e = hipMemcpyAsync(&total_groups, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpyAsync(ctx->mailbox, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(ctx->stream);
+            total_groups = ctx->mailbox[0];
             if (e != hipSuccess) {
                 set_err("leaves: %s", hipGetErrorString(e));
                 rc = DNAGPU_ERR_HIP;
@@ -2307,8 +2343,7 @@ extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64
             HIP_TRY(launch_hist_summary(p->keys, p->counts, p->extent ? p->extent : p->n_distinct, res, ctx->stream));
     }
     u64 r[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(r, res, 24, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    RC_TRY(read_back(ctx, r, res, 24));
     if (total) *total = r[0];
     if (unique) *unique = r[1];
     if (checksum) *checksum = r[2];
