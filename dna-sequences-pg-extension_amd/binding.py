@@ -570,7 +570,7 @@ class Context:
 
 
 MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
-MULTI_OPT_PARTS, MULTI_OPT_EMULATE_LINK_GBS = 1, 2
+MULTI_OPT_PARTS, MULTI_OPT_EMULATE_LINK_GBS, MULTI_OPT_PROBE_OWNER = 1, 2, 3
 
 
 class _BorrowedContext(Context):
@@ -610,6 +610,10 @@ class Multi:
     def emulate_link(self, gb_per_s):
         """rehearsal on one device: inbound pieces are held to this rate on the transfer stream (0 = off)"""
         _chk(lib().dnagpu_multi_set_option(self.h, MULTI_OPT_EMULATE_LINK_GBS, float(gb_per_s)))
+
+    def probe_owner(self, owner):
+        """rehearsal on one device: only this owner pulls and counts (-1: all), so that last_times() are its own"""
+        _chk(lib().dnagpu_multi_set_option(self.h, MULTI_OPT_PROBE_OWNER, float(owner)))
 
     def last_times(self):
         t = _MultiTimes()

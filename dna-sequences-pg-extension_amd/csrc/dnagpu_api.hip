@@ -2583,6 +2583,7 @@ struct dnagpu_multi {
     std::vector<hipStream_t> xfer;        // per rank: the stream its inbound record copies are queued on
     int parts = DNAGPU_MULTI_DEFAULT_PARTS;   // bucket groups per owner of the pipelined exchange
     double emulate_gbs = 0;               // rehearsal: same-device "transfers" are held to this rate (0 = off)
+    int probe_owner = -1;                 // rehearsal: only this owner pulls and counts (-1 = all), so that its time is its own
 };
 
 struct dnagpu_multi_dna {
@@ -3044,6 +3045,11 @@ extern "C" int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value
             return DNAGPU_ERR_BAD_ARG;
         m->emulate_gbs = value;
         return DNAGPU_OK;
+    case DNAGPU_MULTI_OPT_PROBE_OWNER:
+        if (value < -1 || value >= m->n)
+            return DNAGPU_ERR_BAD_ARG;
+        m->probe_owner = (int)value;
+        return DNAGPU_OK;
     }
     return DNAGPU_ERR_BAD_ARG;
 }
@@ -3178,13 +3184,44 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
                 }
             };
             split(0, nb, W, ocut.data());
-            for (int o = 0; o < W; o++)
-                split(ocut[(size_t)o], std::max(ocut[(size_t)o + 1], ocut[(size_t)o]), P, &cuts[(size_t)o * P]);
+            // An owner's groups grow geometrically (1 : 3 : 9 ...): the first one lands -- and its counting starts --
+            // after a small share of the transfer, and every later group is still in flight while a group a third of its
+            // size is being counted.
+            for (int o = 0; o < W; o++) {
+                const u32 lo = ocut[(size_t)o], hi = std::max(ocut[(size_t)o + 1], ocut[(size_t)o]);
+                u64 tot = 0;
+                for (u32 b = lo; b < hi; b++)
+                    tot += wgt[b];
+                double wsum = 0, acc = 0, wp = 1;
+                for (int p = 0; p < P; p++, wp *= 3)
+                    wsum += wp;
+                u32 *out = &cuts[(size_t)o * P];
+                out[0] = lo;
+                u64 run = 0;
+                u32 b = lo;
+                wp = 1;
+                for (int p = 1; p < P; p++, wp *= 3) {
+                    acc += wp;
+                    const double target = (double)tot * acc / wsum;
+                    while (b < hi && (double)run + (double)wgt[b] / 2 <= target) {
+                        run += wgt[b];
+                        b++;
+                    }
+                    out[p] = b;
+                }
+                cuts[(size_t)(o + 1) * P] = hi;
+            }
         }
         m->last.parts = P;
         const std::function<void(int)> own = [&](int o) {
             const auto t0 = std::chrono::steady_clock::now();
             dnagpu_ctx *c = m->ctx[(size_t)o];
+            if (m->probe_owner >= 0 && o != m->probe_owner) {     // rehearsal probe: this owner's buckets are not counted
+                hists[o] = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, false};
+                if (!hists[o])
+                    fail(o, DNAGPU_ERR_OOM, "host allocation failed");
+                return;
+            }
             hipStream_t xs = m->xfer[(size_t)o];
             hipError_t e = hipSetDevice(c->device);
             if (e != hipSuccess)
@@ -3340,7 +3377,7 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
             }
         m->last.records_ms = *std::max_element(t_rec.begin(), t_rec.end());
         m->last.exchange_ms = *std::max_element(t_xfer.begin(), t_xfer.end());
-        m->last.hidden_ms = *std::min_element(t_hidden.begin(), t_hidden.end());
+        m->last.hidden_ms = m->probe_owner >= 0 ? t_hidden[(size_t)m->probe_owner] : *std::min_element(t_hidden.begin(), t_hidden.end());
         m->last.count_ms = ms_since(t_own);
         for (int r = 0; r < W; r++)
             m->last.bytes_moved += moved[(size_t)r];

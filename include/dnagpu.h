@@ -337,11 +337,15 @@ int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, i
  *                                      DNAGPU_MULTI_MAX_PARTS (1 = all pieces first, then one count)
  *   DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  rehearsal aid for ranks that share one device: every group of inbound pieces is
  *                                      followed, on the transfer stream, by the time the same bytes would take at this
- *                                      many GB/s (0 = off, the default) -- timing only, results are unaffected */
+ *                                      many GB/s (0 = off, the default) -- timing only, results are unaffected
+ *   DNAGPU_MULTI_OPT_PROBE_OWNER       rehearsal aid: only this owner (0 .. n-1) pulls and counts its buckets, the other
+ *                                      ranks' histograms stay empty, so that on a shared device the call's times are one
+ *                                      owner's own (-1 = off, the default: every owner counts) */
 #define DNAGPU_MULTI_OPT_PARTS             1
 #define DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  2
+#define DNAGPU_MULTI_OPT_PROBE_OWNER       3
 #define DNAGPU_MULTI_MAX_PARTS             8
-#define DNAGPU_MULTI_DEFAULT_PARTS         2
+#define DNAGPU_MULTI_DEFAULT_PARTS         3
 int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value);
 
 /* Host wall-clock milliseconds of the most recent dnagpu_count_multi_unordered call on m, per phase, the slowest rank of
