@@ -456,12 +456,16 @@ hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunk
 // prefixes over chunks (per digit) and store the per-digit totals in tot[row of the first chunk].
 // Grid = (n_chunks, ROW_STRIDE/64); only the workgroup of a node's first chunk works.
 constexpr int PF_SLICES = 16;                           // chunk slices per digit (threads = 64 digits x slices)
-__global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slices, const Node *__restrict__ nodes,
+// DIG digits per workgroup: 64 for levels of many nodes; 16 when one node holds thousands of chunks (a root): four times
+// the workgroups and a quarter of the chunks per thread -- the kernel is a chain of dependent L2 reads per thread (the
+// root's 4096 rows at 64 x 16: 85 - 116 us per level; at 16 x 64: ~25 us).
+template <int DIG>
+__global__ __launch_bounds__(1024) void level_prefix_kernel(int n_slices, const Node *__restrict__ nodes,
                                                            const Chunk *__restrict__ chunks, u32 n_chunks,
                                                            u32 chunk_len, u32 *__restrict__ hist,
                                                            u32 *__restrict__ tot)
 {
-    __shared__ u32 part[PF_SLICES][64];
+    __shared__ u32 part[1024 / DIG][DIG];
     const u32 c0 = blockIdx.x;
     if (c0 >= n_chunks)
         return;
@@ -470,11 +474,12 @@ __global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slic
         return;                                   // not the node's first chunk
     const Node nd = nodes[ch.node];
     const u32 R = 1u << nd.split;
-    const u32 d = blockIdx.y * 64 + (threadIdx.x & 63);
-    if (blockIdx.y * 64 >= R)
+    const u32 dl = threadIdx.x % DIG;
+    const u32 d = blockIdx.y * DIG + dl;
+    if (blockIdx.y * DIG >= R)
         return;
     const u32 nc = (nd.len + chunk_len - 1) / chunk_len;
-    const u32 slice = threadIdx.x >> 6;
+    const u32 slice = threadIdx.x / DIG;
     const u32 per = (nc + n_slices - 1) / n_slices;
     const u32 cb = slice * per < nc ? slice * per : nc;
     const u32 ce = cb + per < nc ? cb + per : nc;
@@ -483,11 +488,11 @@ __global__ __launch_bounds__(64 * PF_SLICES) void level_prefix_kernel(int n_slic
     if (live)
         for (u32 c = cb; c < ce; c++)
             sum += hist[(u64)(c0 + c) * ROW_STRIDE + d];
-    part[slice][threadIdx.x & 63] = sum;
+    part[slice][dl] = sum;
     __syncthreads();
     u32 base = 0, total = 0;
     for (u32 s = 0; s < (u32)n_slices; s++) {
-        u32 t = part[s][threadIdx.x & 63];
+        u32 t = part[s][dl];
         if (s < slice)
             base += t;
         total += t;
@@ -633,9 +638,14 @@ hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chu
 {
     if (n_chunks == 0)
         return hipSuccess;
-    // few nodes with many chunks each (the dna root): 16 chunk slices per digit; else 4
+    // few nodes with many chunks each (the dna root): 64 chunk slices of 16 digits; else 64 digits x 16 or 4 slices
+    if (n_split_nodes == 1 && n_chunks > 512) {       // (one split node: its chunks are all the chunks, the first is chunk 0)
+        hipLaunchKernelGGL(level_prefix_kernel<16>, dim3(1, ROW_STRIDE / 16), dim3(1024), 0, s, 64, nodes, chunks, n_chunks,
+                           chunk_len, hist, tot);
+        return hipGetLastError();
+    }
     const int slices = n_split_nodes > 0 && n_chunks / n_split_nodes > 32 ? PF_SLICES : 4;
-    hipLaunchKernelGGL(level_prefix_kernel, dim3(n_chunks, ROW_STRIDE / 64), dim3(64 * slices), 0, s, slices, nodes, chunks,
+    hipLaunchKernelGGL(level_prefix_kernel<64>, dim3(n_chunks, ROW_STRIDE / 64), dim3(64 * slices), 0, s, slices, nodes, chunks,
                        n_chunks, chunk_len, hist, tot);
     return hipGetLastError();
 }
