@@ -12,6 +12,7 @@ The directory name has a hyphen (it mirrors the reference's name), so it is load
 """
 from .binding import (  # noqa: F401
     DEBUG_FORCE_SUPERKMER,
+    DEBUG_GUARD_POOL,
     DEBUG_HEAVY_EXPAND,
     Context,
     Dna,

@@ -23,6 +23,19 @@ ERR_DNA_INVALID_CHAR = 12
 DEBUG_POISON_POOL = 1
 DEBUG_FORCE_SUPERKMER = 2
 DEBUG_HEAVY_EXPAND = 4
+DEBUG_GUARD_POOL = 8
+
+
+def _env_debug():
+    """test-harness switches (this wrapper is test / bench tooling): DNAGPU_TEST_POISON=1 runs every context with
+    DNAGPU_DEBUG_POISON_POOL (all work buffers pre-filled with 0xFF), DNAGPU_TEST_GUARD=1 with DNAGPU_DEBUG_GUARD_POOL
+    (a guard band behind every work buffer, checked whenever a histogram, a sequence or a buffer is freed)"""
+    f = 0
+    if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0"):
+        f |= DEBUG_POISON_POOL
+    if os.environ.get("DNAGPU_TEST_GUARD", "0") not in ("", "0"):
+        f |= DEBUG_GUARD_POOL
+    return f
 
 FILTER_EQUALS = 1
 FILTER_STARTS_WITH = 2
@@ -325,6 +338,8 @@ class Hist:
 
     def free(self):
         if self.h:
+            if self.ctx._base_debug & DEBUG_GUARD_POOL:
+                self.ctx.synchronize()          # raises if a kernel wrote past the end of a work buffer
             lib().dnagpu_hist_free(self.ctx.h, self.h)
             self.h = None
 
@@ -335,7 +350,7 @@ class Context:
         _chk(lib().dnagpu_init(device, C.byref(self.h)))
         # test harness switch (this wrapper is test/bench tooling): DNAGPU_TEST_POISON=1 runs every context
         # with DNAGPU_DEBUG_POISON_POOL, i.e. all work buffers pre-filled with 0xFF
-        self._base_debug = DEBUG_POISON_POOL if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0") else 0
+        self._base_debug = _env_debug()
         if self._base_debug:
             self.set_debug(0)
 
@@ -580,7 +595,7 @@ class _BorrowedContext(Context):
         self.h = C.c_void_p(handle)
         # the same test-harness switch as Context: the rank contexts of a Multi are created in C, so the poison flag
         # is set on them here
-        self._base_debug = DEBUG_POISON_POOL if os.environ.get("DNAGPU_TEST_POISON", "0") not in ("", "0") else 0
+        self._base_debug = _env_debug()
         if self._base_debug:
             self.set_debug(0)
 

@@ -107,7 +107,9 @@ struct PoolBlock {
     void *ptr;
     size_t size;
     bool in_use;
+    size_t guard_at = 0;      // DNAGPU_DEBUG_GUARD_POOL: offset of the block's guard band (0 = none)
 };
+constexpr size_t POOL_GUARD = 256;               // bytes of 0xA5 behind the bytes a caller asked for
 
 struct dnagpu_ctx {
     int device;
@@ -199,21 +201,32 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
 {
     if (bytes == 0)
         bytes = 256;
-    bytes = (bytes + 255) & ~(size_t)255;
+    const size_t asked = bytes;
+    const bool guard = (ctx->debug_flags & DNAGPU_DEBUG_GUARD_POOL) != 0;
+    bytes = (bytes + (guard ? POOL_GUARD : 0) + 255) & ~(size_t)255;
+    const size_t want = bytes;
+    auto finish = [&](PoolBlock &b) -> int {
+        b.in_use = true;
+        b.guard_at = 0;
+        *out = b.ptr;
+        RC_TRY(pool_poison(ctx, b.ptr, b.size));
+        if (guard) {      // the band sits right behind the bytes asked for (a recycled block may be larger)
+            HIP_TRY(hipMemsetAsync(static_cast<char *>(b.ptr) + asked, 0xA5, POOL_GUARD, ctx->stream));
+            b.guard_at = asked;
+        }
+        return DNAGPU_OK;
+    };
     int best = -1;
     for (size_t i = 0; i < ctx->pool.size(); i++) {
         PoolBlock &b = ctx->pool[i];
-        if (!b.in_use && b.size >= bytes && b.size <= bytes * 2 + (1u << 20))
+        if (!b.in_use && b.size >= want && b.size <= want * 2 + (1u << 20))
             if (best < 0 || b.size < ctx->pool[best].size)
                 best = (int)i;
     }
-    if (best >= 0) {
-        ctx->pool[best].in_use = true;
-        *out = ctx->pool[best].ptr;
-        return pool_poison(ctx, ctx->pool[best].ptr, ctx->pool[best].size);
-    }
+    if (best >= 0)
+        return finish(ctx->pool[best]);
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         // give pooled-but-idle memory back and retry once
         (void)hipGetLastError();
@@ -226,16 +239,35 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
                 i++;
             }
         }
-        e = hipMalloc(&p, bytes);
+        e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        set_err("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        set_err("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         return DNAGPU_ERR_OOM;
     }
-    ctx->pool.push_back(PoolBlock{p, bytes, true});
-    *out = p;
-    return pool_poison(ctx, p, bytes);
+    ctx->pool.push_back(PoolBlock{p, want, true});
+    return finish(ctx->pool.back());
+}
+
+// DNAGPU_DEBUG_GUARD_POOL: every guard band must still hold its pattern (checked with the stream idle)
+static int pool_check_guards(dnagpu_ctx *ctx)
+{
+    if (!(ctx->debug_flags & DNAGPU_DEBUG_GUARD_POOL))
+        return DNAGPU_OK;
+    unsigned char band[POOL_GUARD];
+    for (const PoolBlock &b : ctx->pool) {
+        if (!b.guard_at)
+            continue;
+        HIP_TRY(hipMemcpy(band, static_cast<const char *>(b.ptr) + b.guard_at, POOL_GUARD, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < POOL_GUARD; i++)
+            if (band[i] != 0xA5) {
+                set_err("pool guard: a kernel wrote %zu bytes past the end of a %zu-byte work buffer (%s)", i + 1, b.guard_at,
+                        b.in_use ? "in use" : "already returned");
+                return DNAGPU_ERR_INTERNAL;
+            }
+    }
+    return DNAGPU_OK;
 }
 
 // Buffers go back to the pool while kernels that use them may still be queued: every later user is
@@ -355,7 +387,7 @@ extern "C" int dnagpu_synchronize(dnagpu_ctx *ctx)
     if (!ctx)
         return DNAGPU_ERR_BAD_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return DNAGPU_OK;
+    return pool_check_guards(ctx);                  // (DNAGPU_DEBUG_GUARD_POOL only)
     });
 }
 

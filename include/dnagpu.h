@@ -383,6 +383,11 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * older path, still what records received from other ranks take when most of them are heavy) instead of splitting
  * them with the chunked level kernels. */
 #define DNAGPU_DEBUG_HEAVY_EXPAND 4u
+/* DNAGPU_DEBUG_GUARD_POOL: every work buffer the pool hands out is followed by a 256-byte guard band of 0xA5 bytes, placed
+ * right behind the bytes that were asked for; dnagpu_synchronize() then checks every band (of buffers in use and of
+ * buffers already returned) and fails with DNAGPU_ERR_INTERNAL -- dnagpu_last_error() names the buffer's size -- if a
+ * kernel wrote past the end of one.  Complements DNAGPU_DEBUG_POISON_POOL (reads of memory a call never wrote). */
+#define DNAGPU_DEBUG_GUARD_POOL 8u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

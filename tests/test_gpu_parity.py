@@ -971,6 +971,27 @@ def test_count_records_big_buckets(ctx, pkg, kind):
     ctx.buffer_free(buf)
 
 
+def test_pool_guard_bands_catch_a_write_past_the_end(pkg):
+    """DNAGPU_DEBUG_GUARD_POOL: a write past the end of a work buffer -- here made on purpose through
+    dnagpu_buffer_upload -- fails the next dnagpu_synchronize, naming the buffer's size; a clean run does not."""
+    with pkg.Context(0) as c:
+        c.set_debug(pkg.DEBUG_GUARD_POOL)
+        d = c.synth(3, 300_000)
+        h = c.count_kmers_unordered(d, 31)
+        c.synchronize()                                   # every band of the count's work buffers is intact
+        h.free()
+        buf = c.buffer_alloc(1000)                        # 125 words
+        c.upload_u64(buf, np.arange(125, dtype=np.uint64))
+        c.synchronize()
+        c.upload_u64(buf, np.arange(126, dtype=np.uint64))   # one word too many
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            c.synchronize()
+        assert "past the end of a 1000-byte" in str(ei.value)
+        c.set_debug(0)
+        c.buffer_free(buf)
+        d.free()
+
+
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
