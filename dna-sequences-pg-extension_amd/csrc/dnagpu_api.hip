@@ -1519,10 +1519,10 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
                 heavy_idx.push_back(i);
                 heavy->total += kc[i];
             }
-        // a sequence that is mostly repeats (poly-A, satellites over more than half of it) is cheaper through the tree
-        // from scratch
-        // (with DNAGPU_DEBUG_HEAVY_EXPAND, the path of the tests, a sequence that is mostly repeats is cheaper through the
-        // tree from scratch; the chunked split below has no such limit)
+        // DNAGPU_SK_SKEWED leaves this function in two cases only: with DNAGPU_DEBUG_HEAVY_EXPAND (the older path, kept for
+        // the tests: heavy mid buckets are expanded as a whole, and a set that is mostly heavy is cheaper through the tree
+        // from scratch -- count_core -- or as one key node per coarse bucket -- count_sk_received), or with more heavy mid
+        // buckets than the chunked split below plans for (32768: not reachable with 2^32 rows, a guard).
         if (((ctx->debug_flags & DNAGPU_DEBUG_HEAVY_EXPAND) && heavy->total * 2 > run) || heavy_idx.size() > 32768)
             return DNAGPU_SK_SKEWED;
     }
@@ -1911,7 +1911,6 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     }
     prof_begin(ctx);
     int rc;
-    bool sorted = true;                          // segments in ascending key order (false: bucket order of the super-k-mer engine)
     const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && n >= 64;
     if (any_order && dna && fixed_bits == 0 && n_owners == 1 && ((k >= SK_MIN_K && n >= SK_MIN_ROWS) || force_sk)) {
         rc = count_sk(ctx, dna, first, n, k, h);
@@ -1995,9 +1994,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             }
             rc = run_tree(ctx, ps, dna, first, n, k, keys_in, obits, &tr, 0, 0, false, d_lo, span, tb);
         } else {
-            const bool done = false;
-            if (!done)
-                rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
+            rc = run_tree(ctx, ps, dna, first, n, k, keys_in, 0, &tr, fixed_bits, fixed_prefix);
         }
         u64 *cursor = nullptr, *seg_off = nullptr;
         u32 *seg_cnt = nullptr;
@@ -2013,7 +2010,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &ok);
         if (rc == DNAGPU_OK) rc = ps.alloc((size_t)cap, &oc);
         u32 *flags = nullptr, *scan_tmp = nullptr, *cls_list = nullptr;
-        if (rc == DNAGPU_OK && (!sorted || (tr.n_tiny != tr.n_nodes && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes))) {
+        if (rc == DNAGPU_OK && tr.n_tiny != tr.n_nodes && tr.n_small != tr.n_nodes && tr.n_big != tr.n_nodes) {
             // a mixed node list: single-key / empty nodes are emitted in bulk, each leaf class gets an index list
             rc = ps.alloc((size_t)tr.n_nodes + 1, &flags);
             if (rc == DNAGPU_OK) rc = ps.alloc((size_t)scan_tmp_words(tr.n_nodes), &scan_tmp);
@@ -2026,7 +2023,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             e = hipMemsetAsync(cursor, 0, 8, ctx->stream);
             if (e == hipSuccess)
                 e = launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off, seg_cnt,
-                                  ok, oc, flags, scan_tmp, cls_list, ctx->stream, !sorted);
+                                  ok, oc, flags, scan_tmp, cls_list, ctx->stream, false);
             prof_mark(ctx, "end");
             if (e == hipSuccess)
                 e = hipMemcpyAsync(ctx->mailbox, cursor, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -2050,7 +2047,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
             h->seg_off = seg_off;
             h->seg_cnt = seg_cnt;
             h->n_segs = tr.n_nodes;
-            h->sorted = sorted;
+            h->sorted = true;                   // segments in ascending key order
             ps.release(ok);
             ps.release(oc);
             ps.release(seg_off);

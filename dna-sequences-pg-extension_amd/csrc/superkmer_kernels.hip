@@ -900,8 +900,13 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
             }
         }
         __syncthreads();
+        // (lane t reads tcnt[t + 1], which lane t + 1 is about to zero: both values into registers first, then the store)
+        u32 adv = 0;
+        if (tid < 16)
+            adv = tcnt[tid + 1] - tcnt[tid];
+        __syncthreads();
         if (tid < 16) {
-            gpos[tid] += tcnt[tid + 1] - tcnt[tid];
+            gpos[tid] += adv;
             tcnt[tid] = 0;
         }
         __syncthreads();
@@ -929,17 +934,22 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 
 // ------------------------------------------------------------------------------------------------
 // sk_count: the leaves of the super-k-mer engine.  A final bucket of at most sk_count_cap() k-mers in at most
-// SKC_MAXREC records is counted straight from its records in the workgroup's LDS hash table (linear probing, 64-bit
-// compare-and-swap; copies of a key are counted in 16-bit halves beside it); the keys a thread was first to insert
-// stay in its registers and leave, with their counts, when the bucket's output range has arrived.  No key of such a
-// bucket ever reaches HBM as a key.
+// SKC_MAXREC records is counted straight from its records in the workgroup's LDS hash table: linear probing over
+// four-byte slots claimed by a 32-bit compare-and-swap, a slot holding 19 bits of fingerprint and the 12-bit id of the
+// k-mer that claimed it; a probe that meets its own fingerprint re-derives the claimant's key from the staged records and
+// compares in full (a copy is counted in a 16-bit counter at the claimant's id).  The keys a thread was first to insert
+// stay in its registers and leave, with their counts, one bucket later; a bucket's output range is the exclusive scan of
+// the buckets' k-mer counts -- no cursor.  No key of such a bucket ever reaches HBM as a key.
 //   Work split: a record's k-mers are cut into groups of SKC_KPT ("quads"); a prefix sum over the records' quad counts
 //   gives every quad a thread, and every record writes its quads' owner entries itself -- no search.  Records and
 //   owner table live in LDS, so that nothing between two barriers waits for global memory: the next bucket's records
-//   are requested a whole bucket ahead, the output range (one atomic add on the global cursor) one bucket behind.
-//   Measured and dropped here: the quad's four first probes issued back to back before any result is examined (18.9 vs
-//   17.8 ms at 3 Gbase: more registers live, a 16-byte spill); eight k-mers per thread at 512 threads (24.7 ms: half
-//   the waves); a binary search over the prefix instead of the owner table (19.6 ms).
+//   are requested a whole bucket ahead.
+//   What bounds it (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
+//   (9.3 G wave instructions at 3 Gbase: VALU issue 77 % busy, the CU's scalar unit 47 %), not the LDS (23 % busy).
+//   Measured and dropped: the quad's four first probes issued back to back (more registers live, a spill); eight k-mers
+//   per thread at 512 threads (half the waves); a binary search over the prefix instead of the owner table; branch-free
+//   probe loops that keep finished lanes probing a private word (more VALU than the SALU they save: 12.7 vs 12.1 ms);
+//   a per-lane `claimed` flag as a bool (it lives in scalar registers: +44 % SALU, 13.8 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
 constexpr int SKC_SLOTS = 236 * 64;              // 15104 four-byte slots (load 0.2 at 3000 keys): with the tables below 79.0 KiB, two workgroups per CU

@@ -886,12 +886,37 @@ def test_records_exchange_one_process(ctx, pkg, world, n, k, motif):
         ctx.count_records([(0, 5, n_buckets)], k, rows)          # a bucket the geometry does not have
 
 
+def test_count_records_mostly_repeats_expand_everything(ctx, pkg):
+    """dnagpu_count_records over records that are almost all heavy (a periodic sequence), with the heavy mid buckets
+    expanded as a whole (DNAGPU_DEBUG_HEAVY_EXPAND): levels 1-2 report the set skewed, every coarse bucket becomes one
+    key node (no final bucket at all) and the ordinary levels count the keys."""
+    k = 27
+    text = ("ACGTTGCAATCCGA" * 25_000) + "".join("ACGT"[(i * 7 + i // 3) % 4] for i in range(50_001))
+    words, n = orc.dna_encode(text)
+    ok, oc = orc.count_kmers(words, n, k)
+    rows = n - k + 1
+    d = ctx.upload(words, n)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_HEAVY_EXPAND)
+    try:
+        r = ctx.sk_records(d, k, 0, rows, rows)
+        pieces = [(r.device_ptr + 16 * int(r.offsets[b]), int(r.offsets[b + 1] - r.offsets[b]), b) for b in range(r.n_buckets)]
+        h = ctx.count_records(pieces, k, rows)
+        hu = ctx.count_kmers_unordered(d, k)          # (the same input through the single-GPU entry point: the tree from scratch)
+    finally:
+        ctx.set_debug(0)
+    assert h.total == rows
+    check_hist_unordered(h, ok, oc, "records of a mostly periodic sequence, everything expanded")
+    check_hist_unordered(hu, ok, oc, "mostly periodic sequence, unordered entry point with HEAVY_EXPAND")
+    for o in (h, hu, r, d):
+        o.free()
+
+
 def test_count_records_fingerprint_collisions(ctx, pkg):
-    """sk_count's table slots hold a 20-bit fingerprint, not the key: keys that share slot AND fingerprint must still be
+    """sk_count's table slots hold a 19-bit fingerprint, not the key: keys that share slot AND fingerprint must still be
     told apart (the claimant's key is re-derived from the staged records and compared in full).  Hand-made records of
-    one k-mer each, all in one final bucket: key ^ (m | m << 32) for m < 128 leaves both the slot hash
-    (a function of lo ^ hi) and the fingerprint (that, xor bits 39.. of the key) unchanged -- 128 distinct keys on one
-    probe chain with one fingerprint -- some of them several times, mixed with random keys."""
+    one k-mer each, all in one final bucket: key ^ (m | m << 32) for m < 128 leaves lo ^ hi, and with it both the slot
+    and the fingerprint (functions of lo ^ hi), unchanged -- 128 distinct keys on one probe chain with one fingerprint --
+    some of them several times, mixed with random keys."""
     k, rows = 31, 50_000_000                       # (rows only fixes the bucket geometry)
     nb = ctx.sk_buckets(rows, k)
     rng = np.random.default_rng(7)
