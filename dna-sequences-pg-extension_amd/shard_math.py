@@ -73,3 +73,22 @@ def bucket_owner_ranges_weighted(weights, world):
         cuts.append(b)
     cuts.append(nb)
     return [(cuts[o], max(cuts[o + 1], cuts[o])) for o in range(world)]
+
+
+def bucket_group_cuts(weights, lo, hi, parts):
+    """An owner's buckets [lo, hi) cut into `parts` groups for the pipelined exchange: the groups grow geometrically
+    (1 : 3 : 9 ... by records), so that the first one lands -- and its counting starts -- after a small share of the
+    transfer (the rule of dnagpu_count_multi_unordered).  Returns parts + 1 cut points."""
+    parts = max(1, int(parts))
+    tot = sum(int(weights[b]) for b in range(lo, hi))
+    wsum = sum(3 ** p for p in range(parts))
+    cuts, run, b, acc = [lo], 0, lo, 0
+    for p in range(1, parts):
+        acc += 3 ** (p - 1)
+        target = tot * acc / wsum
+        while b < hi and run + int(weights[b]) / 2 <= target:
+            run += int(weights[b])
+            b += 1
+        cuts.append(b)
+    cuts.append(hi)
+    return cuts

@@ -26,8 +26,46 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from .shard_math import (OWNER_BITS, bucket_owner_ranges, bucket_owner_ranges_weighted, owner_key_range,  # noqa: F401
-                         shard_ranges, word_chunks)  # (pure arithmetic: no torch)
+from .shard_math import (OWNER_BITS, bucket_group_cuts, bucket_owner_ranges, bucket_owner_ranges_weighted,  # noqa: F401
+                         owner_key_range, shard_ranges, word_chunks)  # (pure arithmetic: no torch)
+
+
+class HistParts:
+    """The histogram of an owner whose buckets were counted group by group (the pipelined record exchange): the same
+    read methods as one histogram, the groups of part i before those of part i + 1."""
+
+    def __init__(self, hists):
+        self.hists = list(hists)
+
+    @property
+    def distinct(self):
+        return sum(h.distinct for h in self.hists)
+
+    @property
+    def total(self):
+        return sum(h.total for h in self.hists)
+
+    @property
+    def is_sorted(self):
+        return False
+
+    def download(self):
+        import numpy as np
+        parts = [h.download() for h in self.hists]
+        if not parts:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def summary(self):
+        t = [0, 0, 0, 0]
+        for h in self.hists:
+            t = [(a + b) & ((1 << 64) - 1) for a, b in zip(t, h.summary())]
+        return tuple(t)
+
+    def free(self):
+        for h in self.hists:
+            h.free()
+        self.hists = []
 
 
 class _DevArray:
@@ -117,15 +155,17 @@ class GpuEngine:
         """phase times of the last sharded count: the record cut (if any) followed by the count"""
         return list(getattr(self, "_phases0", [])) + list(self.ctx.last_phase_times())
 
-    def count_records(self, recv_t, pieces, k, global_rows):
+    def count_records(self, recv_t, pieces, k, global_rows, last=True):
         """pieces: [(offset in records inside recv_t, n_records, bucket)]"""
         torch.cuda.synchronize(self.device)
         base = recv_t.data_ptr() if recv_t.numel() else 0
-        hist = self.ctx.count_records([(base + 16 * off, n, b) for off, n, b in pieces if n], k, global_rows)
+        return self.ctx.count_records([(base + 16 * off, n, b) for off, n, b in pieces if n], k, global_rows)
+
+    def release_records(self):
+        """the rank's own records (the send buffer of the exchange) go back to the pool"""
         if getattr(self, "_records", None) is not None:
             self._records.free()
             self._records = None
-        return hist
 
 
 def gather_sequence(chunk_t, world, engine, always=False):
@@ -192,11 +232,14 @@ def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None,
     return hist, dna
 
 
-def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False):
+def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False, parts=3):
     """The record-exchange variant (k >= 23): rank r cuts the super-k-mer records of its OWN rows only, every coarse
-    bucket goes to its owner with one all-to-all (1.8 bytes per k-mer at k = 31; nothing is swept twice and no rank
-    touches the whole sequence), and the owner counts the records it received.  The ranks' histograms are disjoint
-    (a k-mer's bucket depends on its content alone) but in no key order.  Returns (hist, dna) like count_sharded."""
+    bucket goes to its owner (1.8 bytes per k-mer at k = 31; nothing is swept twice and no rank touches the whole
+    sequence), and the owner counts the records it received.  The exchange is PIPELINED with the count like
+    dnagpu_count_multi_unordered's: an owner's buckets travel in `parts` groups (point-to-point sends and receives, all
+    posted at once, group after group), and group g is counted while group g + 1 is still in flight.  The ranks'
+    histograms are disjoint (a k-mer's bucket depends on its content alone) but in no key order.
+    Returns (hist, dna) like count_sharded; hist is a HistParts when more than one group was counted."""
     first, n_mine, base_lo, base_hi = shard_ranges(n_bases, k, world)[rank]
     global_rows = max(n_bases - k + 1, 0)
     if dna is None:
@@ -213,28 +256,56 @@ def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=No
     else:
         dist.all_gather_into_tensor(all_counts, counts)
     all_counts = all_counts.cpu().view(world, n_buckets)
-    # owners: contiguous bucket ranges, balanced by the records the buckets hold (the same split on every rank)
-    owners = bucket_owner_ranges_weighted([int(x) for x in all_counts.sum(dim=0).tolist()], world)
-    lo, hi = owners[rank]
-    # split sizes in int64 words (two per record); what arrives is known from the counts: no size exchange
-    in_splits = [2 * (boffs[min(owners[o][1], n_buckets)] - boffs[min(owners[o][0], n_buckets)]) for o in range(world)]
-    out_splits = [2 * int(all_counts[src, lo:hi].sum()) for src in range(world)]
-    if world == 1 and not always_collective:
-        recv = send
-    elif via_host and send.is_cuda:                                     # gloo has no device all-to-all (test rig)
-        recv_h = torch.empty(sum(out_splits), dtype=torch.int64)
-        dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits)
-        recv = engine.empty(sum(out_splits))
-        recv.copy_(recv_h)
-    else:
-        recv = engine.empty(sum(out_splits))
-        dist.all_to_all_single(recv, send, out_splits, in_splits)
-    pieces, pos = [], 0
-    for src in range(world):                                            # the all-to-all delivers source after source
-        for b in range(lo, hi):
-            n = int(all_counts[src, b])
-            pieces.append((pos, n, b))
-            pos += n
-    assert 2 * pos == recv.numel(), (pos, recv.numel())
-    hist = engine.count_records(recv, pieces, k, global_rows)
-    return hist, dna
+    # owners: contiguous bucket ranges, balanced by the records the buckets hold (the same split on every rank); every
+    # owner's range in `parts` groups (the same cuts on every rank, too)
+    weights = [int(x) for x in all_counts.sum(dim=0).tolist()]
+    owners = bucket_owner_ranges_weighted(weights, world)
+    gcuts = [bucket_group_cuts(weights, lo_o, hi_o, parts) for lo_o, hi_o in owners]
+    n_groups = max(1, int(parts))
+    staged = via_host and send.is_cuda                                  # gloo has no device transport (test rig)
+    send_x = send.cpu() if staged else send
+    recv_bufs, reqs_of = [], []
+    for g in range(n_groups):
+        g_lo, g_hi = gcuts[rank][g], gcuts[rank][g + 1]
+        sizes = [2 * int(all_counts[src, g_lo:g_hi].sum()) for src in range(world)]
+        buf = torch.empty(max(sum(sizes), 1), dtype=torch.int64, device=send_x.device)[:sum(sizes)]
+        ops, at = [], 0
+        for q in range(world):
+            src = (rank + q) % world                                    # (own piece first)
+            seg = buf[sum(sizes[:src]):sum(sizes[:src]) + sizes[src]]
+            if src == rank:
+                o_lo, o_hi = gcuts[rank][g], gcuts[rank][g + 1]
+                if sizes[src]:
+                    seg.copy_(send_x[2 * boffs[o_lo]:2 * boffs[o_hi]])
+            elif sizes[src]:
+                ops.append(dist.P2POp(dist.irecv, seg, src))
+        for q in range(1, world):
+            dst = (rank + q) % world
+            d_lo, d_hi = gcuts[dst][g], gcuts[dst][g + 1]
+            if boffs[d_hi] > boffs[d_lo]:
+                ops.append(dist.P2POp(dist.isend, send_x[2 * boffs[d_lo]:2 * boffs[d_hi]], dst))
+        reqs_of.append(dist.batch_isend_irecv(ops) if ops else [])
+        recv_bufs.append((buf, sizes, g_lo, g_hi))
+    hists = []
+    for g in range(n_groups):
+        for r in reqs_of[g]:
+            r.wait()
+        buf, sizes, g_lo, g_hi = recv_bufs[g]
+        if buf.numel() == 0:
+            continue
+        if staged:
+            dev = engine.empty(buf.numel())
+            dev.copy_(buf)
+            buf = dev
+        pieces, pos = [], 0
+        for src in range(world):                                        # the pieces lie source after source
+            for b in range(g_lo, g_hi):
+                n = int(all_counts[src, b])
+                pieces.append((pos, n, b))
+                pos += n
+        assert 2 * pos == buf.numel(), (pos, buf.numel())
+        hists.append(engine.count_records(buf, pieces, k, global_rows, last=(g == n_groups - 1)))
+    engine.release_records()
+    if not hists:
+        hists.append(engine.count_records(engine.empty(0), [], k, global_rows, last=True))
+    return (hists[0] if len(hists) == 1 else HistParts(hists)), dna

@@ -100,7 +100,10 @@ class OracleEngine:
         recs[1::2] = 1
         return torch.from_numpy(recs.view(np.int64).copy()), offs
 
-    def count_records(self, recv_t, pieces, k, global_rows):
+    def release_records(self):
+        pass
+
+    def count_records(self, recv_t, pieces, k, global_rows, last=True):
         recs = recv_t.numpy().view(np.uint64)
         assert sum(n for _, n, _ in pieces) * 2 == recs.size
         keys = recs[0::2]
