@@ -338,7 +338,8 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
 {
     __shared__ u32 gpos[SK_MAX_C0];               // where the chunk's next record of each digit goes (all waves: LDS adds)
     __shared__ u64 wsh_all[SK_NT / 64][66];       // per wave: the tile's packed words -- record payloads are cut from here
-    __shared__ u64 list_all[SK_NT / 64][SKW_LIST + 64];   // per wave: hmin << 32 | start row << 5 | (len-1); + an entry per lane for writes that list nothing
+    __shared__ u64 list_all[SK_NT / 64][SKW_LIST + 64];   // per wave: the tile's records (see below); + an entry per lane for writes that list nothing
+    __shared__ u32 ns_all[SK_NT / 64][64];         // per wave and lane: start row of the run that is open at the lane's first row
     if (blockIdx.x >= n_chunks)
         return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         gpos[d] = trow[d] + hrow[d];
     __syncthreads();
     u64 *wsh = wsh_all[wave], *wl = list_all[wave];
+    u32 *ns_tab = ns_all[wave];
     const u64 below = ((u64)1 << lane) - 1;
     for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
@@ -361,59 +363,27 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         // would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the list
         // (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
         // fit (8 x 63 records).
-        int n_pass = 1;
-        bool plain = f.plain;
-        sk_front_open<W>(f, lmax);
-        for (int pass = 0; pass < n_pass; pass++) {
-            const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
-            u32 wrun = 0;                          // wave-uniform: records listed
-            if (plain) {
-                // records = natural runs: no branch per row -- a lane whose row ends nothing (and lane 63, which owns no
-                // rows) writes to an entry of its own behind the list; so does whatever would overflow the list (the tile
-                // is then redone in four passes by the general walk)
-                const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
-                const u32 dummy = (u32)SKW_LIST + (u32)lane;
-                u32 start = f.ns0;
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
-                    const u32 row = (u32)lane * 32 + (u32)j;
-                    const bool end = nxt != f.hm[j] && lane < 63;
-                    const u64 b = __ballot(end);
-                    const u32 pos = wrun + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
-                    wl[end ? min(pos, (u32)SKW_LIST + 63u) : dummy] = ((u64)f.hm[j] << 32) | (u64)((start << 5) | (row - start));
-                    start = end ? row + 1 : start;
-                    wrun += (u32)__popcll(b);
-                }
-                plain = false;                     // (if the list overflowed: the general walk below)
-            } else
-            sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
-                const bool end = end_any && j >= jlo && j < jhi;
-                const u64 b = __ballot(end);
-                if (end) {
-                    const u32 pos = wrun + (u32)__popcll(b & below);
-                    if (pos < (u32)SKW_LIST)
-                        wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 5) | (u64)(len - 1);
-                }
-                wrun += (u32)__popcll(b);
-            });
-            if (wrun > (u32)SKW_LIST) {            // (only possible in the single pass)
-                n_pass = 4;
-                pass = -1;
-                sk_wave_fence();
-                continue;
-            }
-            sk_wave_fence();                       // list and words written by other lanes of this wave
+        // list entry: hmin << 32 | start row << 16 | end row; start = 0xFFFF: the run started in an earlier lane (ns_tab)
+        auto build = [&](u32 wrun) {              // every lane builds and stores the records of its share of the list
             if (!SK_DBG(2))
                 for (u32 e = (u32)lane; e < wrun; e += 64) {
                     const u64 en = wl[e];
                     const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
                     const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
-                    const u32 len = ((u32)en & 31u) + 1u;
-                    const u32 q = ((u32)(en >> 5) & 0x7FFu) + fo;  // first base of the run, relative to the tile's first word
-                    const u32 wi = q >> 5, sh = (q & 31u) * 2u;
+                    const u32 end_row = (u32)en & 0xFFFFu;
+                    u32 start = ((u32)en >> 16) & 0xFFFFu;
+                    start = start == 0xFFFFu ? ns_tab[end_row >> 5] : start;
+                    const u32 len = end_row - start + 1u;
+                    // the record's 108 payload bits from bit 2 q of the tile's words: six dwords, four funnel shifts
+                    const u32 q = start + fo;      // first base of the run, relative to the tile's first word
+                    const u32 wi = q >> 5, sh = (q & 15u) * 2u;
                     const u64 a0 = wsh[wi], a1 = wsh[wi + 1], a2 = wsh[wi + 2];
-                    u64 lo = funnel(a0, a1, sh), hi = funnel(a1, a2, sh);
+                    const bool odd = (q & 16u) != 0;
+                    const u32 e0 = odd ? (u32)(a0 >> 32) : (u32)a0, e1 = odd ? (u32)a1 : (u32)(a0 >> 32),
+                              e2 = odd ? (u32)(a1 >> 32) : (u32)a1, e3 = odd ? (u32)a2 : (u32)(a1 >> 32),
+                              e4 = odd ? (u32)(a2 >> 32) : (u32)a2;
+                    u64 lo = ((u64)__builtin_amdgcn_alignbit(e2, e1, sh) << 32) | __builtin_amdgcn_alignbit(e1, e0, sh);
+                    u64 hi = ((u64)__builtin_amdgcn_alignbit(e4, e3, sh) << 32) | __builtin_amdgcn_alignbit(e3, e2, sh);
                     const u32 nb = len + (u32)k - 1;
                     if (nb < 32) {
                         lo &= ((u64)1 << (2 * nb)) - 1;
@@ -430,6 +400,61 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     else if (r.x == 0x1234567 && r.y == 0x89)
                         recs[0] = r;
                 }
+        };
+        if (f.plain) {
+            // records = natural runs: no branch per row -- a lane whose row ends nothing (and lane 63, which owns no rows)
+            // writes to an entry of its own behind the list; so does whatever would overflow the list (the tile is then
+            // redone in four passes by the general walk).  A lane does not know where the run that is open at its first
+            // row started: such an entry carries 0xFFFF, and the start -- the last start of the lanes before (a max scan
+            // over the lanes' last starts, one LDS word per lane) -- is looked up when the record is built.
+            const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
+            const u32 dummy = (u32)SKW_LIST + (u32)lane;
+            const u32 r0 = (u32)lane * 32;
+            u32 start = (lane == 0 || f.hm[0] != f.prev_last) ? r0 : 0xFFFFu;
+            u32 wrun = 0;                          // wave-uniform: records listed
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
+                const u32 row = r0 + (u32)j;
+                const bool end = nxt != f.hm[j] && lane < 63;
+                const u64 b = __ballot(end);
+                const u32 pos = wrun + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
+                wl[end ? min(pos, (u32)SKW_LIST + 63u) : dummy] = ((u64)f.hm[j] << 32) | (u64)((start << 16) | row);
+                start = end ? row + 1 : start;
+                wrun += (u32)__popcll(b);
+            }
+            ns_tab[lane] = wave_prev(wave_incl_max(start == 0xFFFFu ? 0u : start));
+            sk_wave_fence();                       // list, words and starts written by other lanes of this wave
+            if (wrun <= (u32)SKW_LIST) {
+                build(wrun);
+                sk_wave_fence();                   // wsh / list are rewritten by the next tile
+                continue;
+            }
+        }
+        // the general walk (a partial tile, runs longer than a record holds, or a list that overflowed: four passes of
+        // eight row positions each always fit)
+        sk_front_open<W>(f, lmax);
+        for (int n_pass = f.plain ? 4 : 1, pass = 0; pass < n_pass; pass++) {
+            const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
+            u32 wrun = 0;
+            sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
+                const bool end = end_any && j >= jlo && j < jhi;
+                const u64 b = __ballot(end);
+                if (end) {
+                    const u32 pos = wrun + (u32)__popcll(b & below);
+                    if (pos < (u32)SKW_LIST)
+                        wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 16) | (u64)end_row;
+                }
+                wrun += (u32)__popcll(b);
+            });
+            if (wrun > (u32)SKW_LIST) {            // (only possible in a single pass)
+                n_pass = 4;
+                pass = -1;
+                sk_wave_fence();
+                continue;
+            }
+            sk_wave_fence();                       // list and words written by other lanes of this wave
+            build(wrun);
             sk_wave_fence();                       // wsh / list are rewritten by the next pass / tile
         }
     }
