@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -123,6 +125,7 @@ struct dnagpu_ctx {
     // pinned, device-visible host words: small results (totals, per-group counts) land here without a
     // staging copy; read after hipStreamSynchronize
     u64 *mailbox;
+    u64 mailbox_seq = 0;      // sequence number of the last flagged read-back (read_back)
     unsigned debug_flags;     // DNAGPU_DEBUG_*
 };
 constexpr size_t MAILBOX_BYTES = (size_t)1 << 20;
@@ -150,11 +153,55 @@ static hipError_t poke(void *dst, const void *src, size_t bytes, hipStream_t st)
 // mailbox and read from there.  A copy into pageable memory (a stack variable, a std::vector) goes through the
 // runtime's staging path, which costs tens of microseconds per call -- a count makes about ten of them.  Waits for
 // the stream.
+// up to 256 bytes go by a one-wave kernel that stores them into the mailbox and then raises a flag word there (system
+// scope): the host polls the flag for a few tens of microseconds -- no completion signal, no wake-up: the copy + wait
+// of a tiny result costs ~20 us through the runtime and a third of that this way -- and falls back to waiting for the
+// stream when the work queued before it takes longer (so a backend does not burn a core through millisecond kernels).
+constexpr size_t MAILBOX_FLAG_WORD = MAILBOX_BYTES / 8 - 1;    // the mailbox's last word
+__global__ void mailbox_kernel(u64 *mailbox, const u32 *src, int n_words, u64 flag_word, u64 seq)
+{
+    u32 *dst = reinterpret_cast<u32 *>(mailbox);
+    if ((int)threadIdx.x < n_words)
+        __hip_atomic_store(&dst[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&mailbox[flag_word], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 static int read_back(dnagpu_ctx *ctx, void *host, const void *dev, size_t bytes)
 {
     if (bytes == 0)
         return DNAGPU_OK;
-    void *to = bytes <= MAILBOX_BYTES ? static_cast<void *>(ctx->mailbox) : host;
+    if (bytes <= 256 && (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(dev) & 3) == 0) {
+        const u64 seq = ++ctx->mailbox_seq;
+        hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->mailbox, static_cast<const u32 *>(dev),
+                           (int)(bytes / 4), (u64)MAILBOX_FLAG_WORD, seq);
+        HIP_TRY(hipGetLastError());
+        volatile u64 *flag = ctx->mailbox + MAILBOX_FLAG_WORD;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (u32 spins = 0;; spins++) {
+            if (*flag == seq) {
+                seen = true;
+                break;
+            }
+            if ((spins & 63) == 63 &&
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+                break;
+        }
+        if (!seen)
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (*flag != seq) {
+            set_err("mailbox: the result of a read-back did not arrive");
+            return DNAGPU_ERR_INTERNAL;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        memcpy(host, ctx->mailbox, bytes);
+        return DNAGPU_OK;
+    }
+    void *to = bytes <= MAILBOX_BYTES - 8 ? static_cast<void *>(ctx->mailbox) : host;
     HIP_TRY(hipMemcpyAsync(to, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (to != host)
@@ -354,6 +401,8 @@ extern "C" int dnagpu_init(int device, dnagpu_ctx **out_ctx)
     ctx->mailbox = nullptr;
     ctx->debug_flags = 0;
     e = hipHostMalloc(reinterpret_cast<void **>(&ctx->mailbox), MAILBOX_BYTES, hipHostMallocDefault);
+    if (e == hipSuccess)
+        memset(ctx->mailbox, 0, MAILBOX_BYTES);
     if (e != hipSuccess) {
         set_err("hipHostMalloc: %s", hipGetErrorString(e));
         hipStreamDestroy(ctx->stream);
@@ -1484,7 +1533,7 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
     {
         const size_t nb = (size_t)l1.n_next * sizeof(u32);
-        if (2 * nb <= MAILBOX_BYTES) {            // both lists through the pinned mailbox, one wait
+        if (2 * nb <= MAILBOX_BYTES - 8) {        // both lists through the pinned mailbox, one wait (its last word is read_back's flag)
             char *mb = reinterpret_cast<char *>(ctx->mailbox);
             HIP_TRY(hipMemcpyAsync(mb, kcount, nb, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(mb + nb, d_lens, nb, hipMemcpyDeviceToHost, st));
