@@ -2714,6 +2714,16 @@ extern "C" int dnagpu_multi_init(const int *devices, int n_gpus, int transport, 
             return rc;
         }
         m->ctx.push_back(c);
+        // the rank's transfer stream, made right behind its context's stream: the runtime hands its hardware queues out
+        // round-robin in creation order, and two streams on one queue would not overlap (seen in the one-device rehearsal
+        // with eight ranks: the pipelined exchange hid nothing when the streams were made in two batches)
+        hipStream_t xs = nullptr;
+        if (hipSetDevice(m->dev[r]) != hipSuccess || hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            dnagpu_multi_destroy(m);
+            return DNAGPU_ERR_HIP;
+        }
+        m->xfer.push_back(xs);
     }
     // peer access for the copy transport and for RCCL's direct xGMI paths (failure is not fatal: copies stage)
     for (int a = 0; a < n_gpus; a++)
@@ -3171,14 +3181,6 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
         return dnagpu_count_multi(m, dna, k, first, count, hists);         // (short k-mers: the ordered paths)
     const auto t_call = std::chrono::steady_clock::now();
     const int W = m->n;
-    // the owners' transfer streams (one per rank, made on first use)
-    while ((int)m->xfer.size() < W) {
-        const int r = (int)m->xfer.size();
-        hipStream_t xs = nullptr;
-        HIP_TRY(hipSetDevice(m->ctx[(size_t)r]->device));
-        HIP_TRY(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
-        m->xfer.push_back(xs);
-    }
     std::vector<dnagpu_records *> recs((size_t)W, nullptr);
     std::vector<int> rcs((size_t)W, DNAGPU_OK);
     std::vector<std::string> errs((size_t)W);
