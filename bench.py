@@ -205,7 +205,8 @@ def main():
 
         def step():
             if use_records:
-                h, state["chunk"] = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, state["chunk"])
+                h, state["chunk"] = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, state["chunk"],
+                                                                      parts=max(args.parts, 1))
             else:
                 # resident input = this rank's word chunk of the packed sequence; the step all-gathers
                 # the chunks (RCCL) and counts the keys this rank owns over the whole sequence

@@ -232,12 +232,13 @@ def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None,
     return hist, dna
 
 
-def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False, parts=3):
+def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False, parts=1):
     """The record-exchange variant (k >= 23): rank r cuts the super-k-mer records of its OWN rows only, every coarse
     bucket goes to its owner (1.8 bytes per k-mer at k = 31; nothing is swept twice and no rank touches the whole
-    sequence), and the owner counts the records it received.  The exchange is PIPELINED with the count like
-    dnagpu_count_multi_unordered's: an owner's buckets travel in `parts` groups (point-to-point sends and receives, all
-    posted at once, group after group), and group g is counted while group g + 1 is still in flight.  The ranks'
+    sequence), and the owner counts the records it received.  parts = 1 (default): one all-to-all, then the count.
+    parts > 1: the exchange is PIPELINED with the count like dnagpu_count_multi_unordered's -- an owner's buckets travel in
+    `parts` groups (point-to-point sends and receives, all posted at once, group after group), and group g is counted
+    while group g + 1 is still in flight (covered by the gloo tests; never run on nccl with more than one rank).  The ranks'
     histograms are disjoint (a k-mer's bucket depends on its content alone) but in no key order.
     Returns (hist, dna) like count_sharded; hist is a HistParts when more than one group was counted."""
     first, n_mine, base_lo, base_hi = shard_ranges(n_bases, k, world)[rank]
@@ -260,6 +261,31 @@ def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=No
     # owner's range in `parts` groups (the same cuts on every rank, too)
     weights = [int(x) for x in all_counts.sum(dim=0).tolist()]
     owners = bucket_owner_ranges_weighted(weights, world)
+    if int(parts) <= 1:
+        # one group: ONE all-to-all (the collective every backend has; what arrives is known from the counts), then the count
+        lo, hi = owners[rank]
+        in_splits = [2 * (boffs[min(owners[o][1], n_buckets)] - boffs[min(owners[o][0], n_buckets)]) for o in range(world)]
+        out_splits = [2 * int(all_counts[src, lo:hi].sum()) for src in range(world)]
+        if world == 1 and not always_collective:
+            recv = send
+        elif via_host and send.is_cuda:                                 # gloo has no device all-to-all (test rig)
+            recv_h = torch.empty(sum(out_splits), dtype=torch.int64)
+            dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits)
+            recv = engine.empty(sum(out_splits))
+            recv.copy_(recv_h)
+        else:
+            recv = engine.empty(sum(out_splits))
+            dist.all_to_all_single(recv, send, out_splits, in_splits)
+        pieces, pos = [], 0
+        for src in range(world):                                        # the all-to-all delivers source after source
+            for b in range(lo, hi):
+                n = int(all_counts[src, b])
+                pieces.append((pos, n, b))
+                pos += n
+        assert 2 * pos == recv.numel(), (pos, recv.numel())
+        hist = engine.count_records(recv, pieces, k, global_rows)
+        engine.release_records()
+        return hist, dna
     gcuts = [bucket_group_cuts(weights, lo_o, hi_o, parts) for lo_o, hi_o in owners]
     n_groups = max(1, int(parts))
     staged = via_host and send.is_cuda                                  # gloo has no device transport (test rig)

@@ -136,7 +136,8 @@ def main():
     if mode == "gather":
         hist, dna = sh.count_sharded(engine, seed, n_bases, k, rank, world, always_collective=True)
     elif mode == "records":
-        hist, dna = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, always_collective=True)
+        hist, dna = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, always_collective=True,
+                                                      parts=int(os.environ.get("SHARD_PARTS", "3")))
     else:
         hist, dna = sh.count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, always_collective=True)
     keys, counts = hist.download()

@@ -19,13 +19,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather", backend="gloo"):
+def run_world(engine, world, n_bases, k, tmp_path, port, mode="gather", backend="gloo", parts=3):
     port = free_port()                      # (the callers' fixed numbers are kept only as labels)
-    out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}_{backend}.json"
+    out = tmp_path / f"res_{engine}_{mode}_{world}_{n_bases}_{k}_{backend}_{parts}.json"
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SHARD_BACKEND=backend)
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SHARD_BACKEND=backend, SHARD_PARTS=str(parts))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_sharded_worker.py"),
                                        engine, str(n_bases), str(k), str(out), mode], env=env))
     for p in procs:
@@ -100,26 +100,30 @@ def test_bucket_owner_ranges_weighted():
     assert sh.bucket_owner_ranges_weighted([0] * 10, 3) == sh.bucket_owner_ranges(10, 3)
 
 
-@pytest.mark.parametrize("world,n_bases,k", [(2, 200_000, 31), (3, 100_001, 25), (2, 5000, 23)])
-def test_sharded_records_gloo_oracle_engine(tmp_path, world, n_bases, k):
-    """the record exchange's host logic (bucket owners, split sizes, piece boundaries) with the oracle standing in"""
-    res = run_world("oracle", world, n_bases, k, tmp_path, 0, "records")
+@pytest.mark.parametrize("world,n_bases,k,parts", [(2, 200_000, 31, 3), (3, 100_001, 25, 3), (2, 5000, 23, 2), (3, 100_001, 25, 1),
+                                                   (2, 200_000, 31, 1)])
+def test_sharded_records_gloo_oracle_engine(tmp_path, world, n_bases, k, parts):
+    """the record exchange's host logic (bucket owners, bucket groups, split sizes, piece boundaries) with the oracle
+    standing in: one all-to-all (parts = 1) and the pipelined point-to-point rounds (parts > 1)"""
+    res = run_world("oracle", world, n_bases, k, tmp_path, 0, "records", parts=parts)
     assert res["ok"] and res["sorted"], res
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n_bases,k", [(2, 3_000_000, 31), (3, 1_000_003, 27), (2, 70_000, 23), (1, 6_000_000, 31)])
-def test_sharded_records_gloo_gpu_engine(tmp_path, world, n_bases, k):
+@pytest.mark.parametrize("world,n_bases,k,parts", [(2, 3_000_000, 31, 3), (3, 1_000_003, 27, 1), (2, 70_000, 23, 2), (1, 6_000_000, 31, 1),
+                                                   (2, 3_000_000, 31, 1)])
+def test_sharded_records_gloo_gpu_engine(tmp_path, world, n_bases, k, parts):
     """count_sharded_exchange_records with the product engine: every rank cuts the records of its own rows
     (dnagpu_sk_records), the buckets travel to their owners, the owners count them (dnagpu_count_records)"""
-    res = run_world("gpu", world, n_bases, k, tmp_path, 0, "records")
+    res = run_world("gpu", world, n_bases, k, tmp_path, 0, "records", parts=parts)
     assert res["ok"] and res["sorted"], res
 
 
 @pytest.mark.gpu
 def test_sharded_records_rccl_one_rank(tmp_path):
-    res = run_world("gpu", 1, 2_000_000, 31, tmp_path, 0, "records", backend="nccl")
-    assert res["ok"] and res["sorted"], res
+    for parts in (1, 3):
+        res = run_world("gpu", 1, 2_000_000, 31, tmp_path, 0, "records", backend="nccl", parts=parts)
+        assert res["ok"] and res["sorted"], res
 
 
 @pytest.mark.gpu
