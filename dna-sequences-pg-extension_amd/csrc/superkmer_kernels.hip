@@ -998,13 +998,13 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
 {
     constexpr int WAVES = SKC_NT / 64;
     constexpr int RWAVES = SKC_MAXREC / 64;        // waves that hold records
-    // A slot holds 20 bits of fingerprint and the 12-bit id of the k-mer that claimed it (thread << 2 | position in its
-    // quad) -- four bytes instead of the key's eight, so the same LDS gives twice the slots and probe chains half as
-    // long (the kernel is bound by LDS instructions per bucket, and a probe chain is as long as its slowest lane's).
-    // An insert that meets its own fingerprint re-derives the claimant's key from the staged records (owner table ->
-    // record -> shift) and compares in full: equal = a copy, counted at the claimant's id; different = a fingerprint
-    // collision (one comparison in 2^20), which just probes on.  No key value is reserved.
-    __shared__ __attribute__((aligned(16))) u32 tab[SKC_SLOTS + 64];   // (+ a word per lane that is never free: see the probe loops)
+    // A slot holds 19 bits of fingerprint (under a clear top bit: no word equals the all-ones of a free slot) and the
+    // 12-bit id of the k-mer that claimed it (thread << 2 | position in its quad) -- four bytes instead of the key's
+    // eight, so the same LDS gives twice the slots and probe chains half as long.  An insert that meets its own
+    // fingerprint re-derives the claimant's key from the staged records (owner table -> record -> shift) and compares in
+    // full: equal = a copy, counted at the claimant's id; different = a fingerprint collision (one comparison in 2^19),
+    // which just probes on.  No key value is reserved.
+    __shared__ __attribute__((aligned(16))) u32 tab[SKC_SLOTS];
     __shared__ __attribute__((aligned(16))) u32 cop2[SKC_NT * SKC_KPT / 2];    // copies per claimant id, 16-bit halves
     unsigned short *cop16 = reinterpret_cast<unsigned short *>(cop2);
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
@@ -1017,8 +1017,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         return;
     for (int q = tid; q < SKC_SLOTS; q += SKC_NT)
         tab[q] = SKC_FREE;
-    if (tid < 64)
-        tab[SKC_SLOTS + tid] = 0;
     for (int q = tid; q < SKC_NT * SKC_KPT / 2; q += SKC_NT)
         cop2[q] = 0;
     if (tid < 2)
@@ -1107,8 +1105,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         const u32 off2 = has_next2 ? list_off[lq2] : off_next;
         const Node nn2 = fin[ln2];
         __syncthreads();                           // A2: lrec[] and ownq[] complete, every slot of the previous bucket reset
-        // ---- this thread's quad.  32-bit arithmetic throughout (the kernel is bound by VALU issue: 343 vector
-        // instructions per wave and bucket in round 2's form, 74 % of the SIMDs' issue slots): the quad's k-mers are cut
+        // ---- this thread's quad.  32-bit arithmetic throughout (the kernel's time follows its instruction count: 343 vector
+        // + 214 scalar instructions per wave and bucket in round 2's form): the quad's k-mers are cut
         // from a three-dword window of the record that moves on two bits per k-mer (three v_alignbit), slot and
         // fingerprint come from one 32-bit product (the slot through a full-rate 24-bit multiply), and the probe loop
         // carries the slot's byte address only -- what a claim leaves behind is assigned once, after the loop.
