@@ -60,8 +60,8 @@ PHASE_BYTES = {
     "scatter": lambda n, d, N: 16.0 * n,            # keys in, keys out
     "leaves": lambda n, d, N: 8.0 * n + 12.0 * d,   # keys in, (u64 key, u32 count) groups out
     "dense": lambda n, d, N: 0.25 * N,              # short k-mers: the packed input per pass
-    # super-k-mer engine (dnagpu_count_kmers_unordered, k >= 23): 16-byte records of ~9 k-mers (runs sharing a
-    # minimizer; mean run length (w + 1) / 2 at window w = k - 14) instead of 8-byte keys
+    # super-k-mer engine (dnagpu_count_kmers_unordered, k >= 21): 16-byte records of ~9 k-mers at k = 31 (runs sharing a
+    # minimizer of m = 15 bases, 13 for k = 21 / 22; mean run length (w + 1) / 2 at window w = k - m + 1) instead of 8-byte keys
     "sk_hist0": lambda n, d, N: 0.25 * N,
     "sk_scatter0": lambda n, d, N: 0.25 * N + 16.0 * n / SK_RUN,
     "sk_hist1": lambda n, d, N: 16.0 * n / SK_RUN,
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--pattern", type=str, default=None, help="config 5: the qkmer pattern (length k)")
     ap.add_argument("--engine", choices=["auto", "tree"], default="auto",
                     help="count configs: auto = dnagpu_count_kmers_unordered (GROUP BY semantics: group order "
-                         "unspecified; super-k-mer partitioning for k >= 23 on long sequences), tree = "
+                         "unspecified; super-k-mer partitioning for k >= 21 on long sequences), tree = "
                          "dnagpu_count_kmers (groups in ascending key order, MSD radix tree)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launcher", choices=["one-process", "torchrun"], default="one-process",
@@ -128,7 +128,7 @@ def main():
     n_bases, k, seed = cfg["n_bases"], cfg["k"], cfg["seed"]
     n_kmers = n_bases - k + 1
     global SK_RUN
-    SK_RUN = (max(k - 14, 1) + 1) / 2.0
+    SK_RUN = (max(k - (15 if k >= 23 else 13) + 1, 1) + 1) / 2.0
     is_filter = cfg["kind"] == "filter"
     if is_filter and world > 1:
         raise SystemExit("config 5 is a single-GPU workload (BASELINE.json)")
@@ -199,7 +199,7 @@ def main():
         state = {"chunk": None}
         # long k-mers, any group order (the single-GPU default's rule): every rank cuts the super-k-mer records of its own
         # rows, the coarse buckets travel to their owners (one all-to-all of 1.8 B per k-mer), the owners count them
-        use_records = args.engine != "tree" and k >= 23
+        use_records = args.engine != "tree" and k >= 21
         extra["exchange"] = ("records: own rows -> super-k-mer records -> all-to-all by coarse bucket -> count" if use_records else
                              "sequence: all-gather of the packed chunks -> every rank counts the key range it owns")
 
@@ -378,7 +378,7 @@ def main_one_process(args):
     n_kmers = n_bases - k + 1
     W = args.gpus
     global SK_RUN
-    SK_RUN = (max(k - 14, 1) + 1) / 2.0
+    SK_RUN = (max(k - (15 if k >= 23 else 13) + 1, 1) + 1) / 2.0
 
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -397,7 +397,7 @@ def main_one_process(args):
     for c in multi.ranks:
         c.set_profiling(True)
     mdna = multi.synth(seed, n_bases)
-    use_records = args.engine != "tree" and k >= 23
+    use_records = args.engine != "tree" and k >= 21
     count_fn = multi.count_unordered if use_records else multi.count
 
     def sync_all():

@@ -1433,9 +1433,9 @@ struct SkGeom {
 static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n, int k)
 {
     SkGeom g;
-    // short k-mers have short runs ((k - 13) / 2 k-mers per record on random sequence): the buckets shrink with them so that
-    // a bucket's records (~450) still fit sk_count's 512-record stage
-    const u64 leaf_mean = std::min<u64>(SK_LEAF_MEAN, 225 * (u64)(k - 13));
+    // short windows make short runs ((k - m + 2) / 2 k-mers per record on random sequence): the buckets shrink with them
+    // so that a bucket's records (~450) still fit sk_count's 512-record stage
+    const u64 leaf_mean = std::min<u64>(SK_LEAF_MEAN, 225 * (u64)(k - sk_minimizer_len(k) + 2));
     const u64 n_final = std::max<u64>(n / leaf_mean, 16);
     const u64 n_mid = (n_final + 15) / 16;
     g.b1 = 1;
@@ -1944,6 +1944,10 @@ constexpr u64 SK_MIN_ROWS = (u64)1 << 25;
 // the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record) and the sequence is: measured at
 // 1 Gbase, tree vs this engine: k = 23 13.4 vs 13.1 ms, 24 13.2 vs 12.4, 25 13.2 vs 12.0, 27 13.2 vs 11.5, 29 13.0 vs 10.8;
 // k = 31: 16 Mbase 0.63 vs 0.63 ms, 64 Mbase 1.32 vs 1.11, 250 Mbase 3.70 vs 3.21, 3 Gbase 42.0 vs 30.5
+// k = 21 and 22 (13-base minimizers: runs of 5 - 5.5 k-mers) are supported by the engine -- the multi-GPU record exchange
+// uses it from k = 21 -- but on one GPU they gain too little to be the default (tools/engine_probe.py, tree vs records:
+// k = 21 1.64 vs 1.58 ms at 100 Mbase, 13.1 vs 13.2 at 1 Gbase, 42.2 vs 44.7 at 3 Gbase; k = 22 1.62 vs 1.50, 13.1 vs 12.2,
+// 42.1 vs 43.4; k = 23 1.62 vs 1.43, 13.0 vs 11.7, 42.1 vs 36.8)
 constexpr int SK_MIN_K = 23;
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
@@ -3100,7 +3104,7 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     });
 }
 
-// ---- the same count without any order promise, for long k-mers (k >= 23): the record exchange from one process.
+// ---- the same count without any order promise, for long k-mers (k >= 21): the record exchange from one process.
 // Rank r cuts the records of the rows that start in its own chunk (one word of halo from its neighbour), every coarse
 // bucket's pieces are pulled by the bucket's owner (peer copies of 16-byte records, 1.8 B per k-mer at k = 31; nothing is
 // gathered and no rank sweeps rows of another), and the owner counts them.  The exchange is PIPELINED with the count: an

@@ -152,6 +152,7 @@ hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u3
 // mid buckets into key nodes.  k in [sk_min_k(), 32]; c0n = coarse buckets, b1bits = bits of d1, r0bits = split
 // bits of the root (2^r0bits >= c0n); records are 16 bytes each.
 int sk_min_k();
+int sk_minimizer_len(int k);          // m: 15 for k >= 23, 13 for k = 21, 22
 int sk_tile_rows();
 int sk_max_c0();          // most coarse buckets the level-0 sweeps support
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,

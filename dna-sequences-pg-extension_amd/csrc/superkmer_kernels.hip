@@ -127,7 +127,8 @@ struct SkFront {
 
 template <int W>
 __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 n_rows,
-                                         u32 lmax, u64 *wsh /* this wave's [66] or null: the tile's words, word 0 = the one holding pos0 */)
+                                         u32 lmax, u32 mmask /* 2 m ones: the m-mer */,
+                                         u64 *wsh /* this wave's [66] or null: the tile's words, word 0 = the one holding pos0 */)
 {
     const int lane = threadIdx.x & 63;
     // the 64 bases from this lane's first row on (pos0 + 32 lane): 4 dwords
@@ -159,7 +160,7 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const int q = (2 * j) >> 5, s = (2 * j) & 31;
-        const u32 v = __builtin_amdgcn_alignbit(d[q + 1], d[q], s) & 0x3FFFFFFFu;   // 15 bases
+        const u32 v = __builtin_amdgcn_alignbit(d[q + 1], d[q], s) & mmask;        // m bases
         a[j] = sk_mix(v);
     }
     // the next lane's first W-1 hashes complete this lane's windows
@@ -285,7 +286,7 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &
 template <int W>
 __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                          const u64 *__restrict__ words, u64 n_words, u64 first,
-                                                         u32 lmax, u32 c0n, u32 b1mask, u32 r0n /* digits of the root's split */,
+                                                         u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n /* digits of the root's split */,
                                                          u32 *__restrict__ hist)
 {
     __shared__ u32 h[SK_MAX_C0 + 64];             // (+ a word per lane for the adds that count nothing)
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
     for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, nullptr);
+        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, mmask, nullptr);
         if (f.plain) {
             // a record ends at every row whose successor has another minimum (lane 62's last row: the tile's end).  No
             // branch per row: a lane whose row ends nothing adds to a word of its own behind the histogram.
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
 template <int W>
 __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                             const u64 *__restrict__ words, u64 n_words, u64 first, int k,
-                                                            u32 lmax, u32 c0n, u32 b1mask, u32 r0n,
+                                                            u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n,
                                                             const u32 *__restrict__ hist, const u32 *__restrict__ tot,
                                                             ull2_t *__restrict__ recs, int dbg)
 {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         const u64 tile_pos = first + ch.off + t0;
         const u32 fo = (u32)(tile_pos & 31);
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, wsh);
+        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, mmask, wsh);
         // The records that end in this tile (usually ~225) are listed in the wave's LDS list (ballot + prefix count per
         // row position: no atomics), and every lane then builds the payloads of its share -- building them where they end
         // would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the list
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2, a3 = up ? 0u : p3;
             u32 w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh),
                 w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
-            const u32 hmask = (u32)(kmask >> 32);                // (k >= 23: the low dword is whole)
+            const u32 hmask = (u32)(kmask >> 32);                // (k >= 21: the low dword is whole)
             const u32 id0 = (u32)tid << 2;
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
@@ -1815,31 +1816,37 @@ static int sk_dbg()
 // launchers
 template <int W>
 static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk *chunks, const u64 *words, u64 n_words,
-                         u64 first, int k, u32 lmax, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs)
+                         u64 first, int k, u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs)
 {
     if (scatter)
         hipLaunchKernelGGL(sk_scatter0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           k, lmax, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg());
+                           k, lmax, mmask, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg());
     else
         hipLaunchKernelGGL(sk_hist0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           lmax, c0n, b1mask, r0n, hist);
+                           lmax, mmask, c0n, b1mask, r0n, hist);
 }
 
-int sk_min_k() { return 15 + 9 - 1; }              // window lengths 9 .. 18: k = 23 .. 32
+// The minimizer's length m: 15 for k >= 23 (windows of 9 .. 18 m-mers), 13 for k = 21 and 22 (windows of 9 and 10: runs of
+// 5 - 5.5 k-mers, 3 bytes per k-mer; 4^13 / 9 ~ 7 M effective minimizer values keep the final buckets even up to 2^32
+// rows).  A function of k alone, so every rank of a sharded count cuts the same records.
+int sk_min_k() { return 21; }
+int sk_minimizer_len(int k) { return k >= 23 ? 15 : 13; }
 
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
                             u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    const int w = k - 15 + 1;
+    const int m = sk_minimizer_len(k);
+    const int w = k - m + 1;
+    const u32 mmask = (1u << (2 * m)) - 1u;
     u32 lmax = (u32)(54 - k + 1);                  // a record holds 54 bases
     if (lmax > 32)
         lmax = 32;
     const u32 b1mask = (1u << b1bits) - 1, r0n = 1u << r0bits;
     if (r0n > (u32)SK_MAX_C0)
         return hipErrorInvalidValue;
-#define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, c0n, b1mask, r0n, hist, tot, recs); break;
+#define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs); break;
     switch (w) {
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16) SK_CASE(17) SK_CASE(18)
     default: return hipErrorInvalidValue;

@@ -233,7 +233,7 @@ def count_sharded_exchange_keys(engine, seed, n_bases, k, rank, world, dna=None,
 
 
 def count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, dna=None, always_collective=False, parts=1):
-    """The record-exchange variant (k >= 23): rank r cuts the super-k-mer records of its OWN rows only, every coarse
+    """The record-exchange variant (k >= 21): rank r cuts the super-k-mer records of its OWN rows only, every coarse
     bucket goes to its owner (1.8 bytes per k-mer at k = 31; nothing is swept twice and no rank touches the whole
     sequence), and the owner counts the records it received.  parts = 1 (default): one all-to-all, then the count.
     parts > 1: the exchange is PIPELINED with the count like dnagpu_count_multi_unordered's -- an owner's buckets travel in

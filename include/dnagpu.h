@@ -261,7 +261,7 @@ int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint6
  * bucket to its owner (1.8 bytes per k-mer instead of 8; the caller's all-to-all), and counts what it receives
  * (dnagpu_count_records): equal k-mers meet because they share the bucket.  global_rows = the rows of the whole
  * count: every rank must pass the same value (it fixes the bucket geometry, and the digits are part of the
- * records).  k in [23, 32]. */
+ * records).  k in [21, 32] (minimizers of 15 bases for k >= 23, of 13 for k = 21 and 22). */
 typedef struct dnagpu_records dnagpu_records;
 /* number of coarse buckets of a count of global_rows rows (0: arguments out of range) */
 int dnagpu_sk_buckets(const dnagpu_ctx *ctx, uint64_t global_rows, int k);
@@ -321,7 +321,7 @@ void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d);
  * result, the other ranks' histograms are empty -- the same concatenation property. */
 int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                        dnagpu_hist **hists);
-/* The same groups with no order promise (PostgreSQL's GROUP BY makes none, test.sql:95-104), for long k-mers (k >= 23;
+/* The same groups with no order promise (PostgreSQL's GROUP BY makes none, test.sql:95-104), for long k-mers (k >= 21;
  * shorter ones go through dnagpu_count_multi): the record exchange above from one process.  Nothing is gathered:
  * rank r cuts the super-k-mer records of the rows that start in its own chunk, the owner of a coarse bucket pulls the
  * bucket's pieces from every rank (peer copies of 16-byte records, 1.8 B per k-mer at k = 31) and counts them.

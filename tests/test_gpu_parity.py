@@ -628,7 +628,8 @@ def check_hist_unordered(hist, ok, oc, what):
 @pytest.mark.parametrize("n,k,first", [(5_000_011, 31, 0), (4_500_000, 32, 0), (6_000_000, 27, 7), (5_000_000, 23, 33),
                                        (9_000_000, 31, 12345), (17_000_029, 31, 0), (40_000_000, 29, 1),
                                        (3_000_000, 24, 0), (3_000_000, 25, 5), (3_000_000, 26, 0), (3_000_000, 28, 31),
-                                       (3_000_000, 30, 0), (70_000, 31, 3), (1_000, 32, 0)])
+                                       (3_000_000, 30, 0), (70_000, 31, 3), (1_000, 32, 0),
+                                       (5_000_011, 21, 0), (4_000_000, 22, 9), (40_000_000, 21, 1), (1_000, 21, 0), (70_000, 22, 3)])
 def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     """dnagpu_count_kmers_unordered on sequences long enough for super-k-mer partitioning: the groups are the
     oracle's (sorted on the host for the comparison); a window that does not start on a word boundary"""
@@ -645,7 +646,7 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     assert h.total == len(keys)
     check_hist_unordered(h, ok, oc, f"unordered n={n} k={k} first={first}")
     h.free()
-    if k >= 23 and len(keys) >= (1 << 25):           # the default choice of engine
+    if k >= 23 and len(keys) >= (1 << 25):           # the default choice of engine (k = 21, 22: the tree, tools/engine_probe.py)
         h = ctx.count_kmers_unordered(d, k, first=first)
         assert not h.is_sorted
         assert h.summary() == orc.hist_summary(ok, oc)
@@ -662,10 +663,12 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
 
 @pytest.mark.parametrize("kind", ["motif1000", "motif37", "motif100000", "polyA", "half-polyA", "quarter-polyA", "AT",
                                   "small-polyA", "small-AT"])
-def test_count_unordered_repeats(ctx, pkg, kind):
+@pytest.mark.parametrize("k", [31, 21])
+def test_count_unordered_repeats(ctx, pkg, kind, k):
     """repeat-rich and low-complexity inputs through the unordered entry: heavy buckets are split further by the
-    ordinary levels; a bucket too heavy for one workgroup sends the whole count to the ordinary engine"""
-    n, k = 6_000_000, 31
+    ordinary levels; a bucket too heavy for one workgroup sends the whole count to the ordinary engine (k = 31: 15-base
+    minimizers; k = 21: 13-base ones)"""
+    n = 6_000_000
     if kind.startswith("motif"):
         words = orc.synth_words_repeat(91, n, int(kind[5:]))
     elif kind == "polyA":
@@ -842,7 +845,7 @@ def test_count_unordered_repeats_at_size(ctx, motif):
 
 @pytest.mark.parametrize("world,n,k,motif", [(1, 3_000_000, 31, 0), (2, 3_000_017, 31, 0), (3, 2_000_003, 27, 0), (8, 5_000_000, 29, 0),
                                              (2, 100_000, 23, 0), (4, 1_000, 32, 0), (2, 4_000_000, 31, 1000), (3, 3_000_000, 31, 7),
-                                             (2, 2_000_000, 25, 1)])
+                                             (2, 2_000_000, 25, 1), (3, 3_000_000, 21, 0), (2, 2_000_000, 22, 1000)])
 def test_records_exchange_one_process(ctx, pkg, world, n, k, motif):
     """dnagpu_sk_records + dnagpu_count_records, the exchange done by hand in one process: every "rank" cuts the records
     of its own rows (its shard + the k-1 base halo, the global row count fixing the bucket geometry), every owner counts
@@ -1057,7 +1060,7 @@ def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
             m.emulate_link(50.0)            # the rehearsal delay kernel on the transfer stream: timing only
         for make in ("synth", "upload"):
             d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
-            for k, first, count in ((31, 0, None), (27, 1000, 2_000_000), (23, 31, None), (32, 0, 1_234_567), (8, 0, None)):
+            for k, first, count in ((31, 0, None), (27, 1000, 2_000_000), (23, 31, None), (32, 0, 1_234_567), (21, 5, None), (8, 0, None)):
                 ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False)[first:None if count is None else first + count])
                 hs = m.count_unordered(d, k, first, count)
                 gk = np.concatenate([h.download()[0] for h in hs])
@@ -1079,7 +1082,7 @@ def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
                     wk, wc = h0.download(a, b - a)
                     assert_same(wk, fk[a:b], "window of a histogram of several parts: keys")
                     assert_same(wc, fc[a:b], "window of a histogram of several parts: counts")
-                if k >= 23:
+                if k >= 21:
                     lt = m.last_times()
                     assert lt["parts"] == parts and lt["total_ms"] > 0
                     if count is None:           # (a window may lie in one rank's chunk: then nothing travels)
