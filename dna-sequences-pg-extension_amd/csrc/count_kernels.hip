@@ -118,15 +118,10 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const Node *__restrict_
         atomicAdd(&ctr->n_over, 1u);
 }
 
-__global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32 n_nodes, int level,
-                                                   u32 chunk_len, u32 *__restrict__ outc,
-                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap)
+// split width of one node (0 = not split at this level); n_over = the level's oversize nodes (levels >= 2)
+__device__ __forceinline__ int plan_bits(const Node &nd, int level, u32 n_over, int l1_cap)
 {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes)
-        return;
-    Node nd = nodes[i];
-    int rem = (int)(nd.meta & 0xff);
+    const int rem = (int)(nd.meta & 0xff);
     int bits = 0;
     if (level < 0) {
         // forced level (multi-GPU owner partition): split the node on -level bits whatever its size
@@ -145,7 +140,7 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
             // a budget of 2^19 new nodes over all the level's oversize nodes allows: a few such nodes split
             // 1024 ways (two more levels instead of ten), a hundred thousand of them only 4 ways (every child
             // is a leaves-kernel iteration: 1024 ways there cost 75 ms at 1 Gbase).
-            const u32 over = ctr->n_over ? ctr->n_over : 1u;
+            const u32 over = n_over ? n_over : 1u;
             const int extra = 31 - __builtin_clz(((1u << 19) / over) | 1u);
             if (want < extra)
                 want = extra;
@@ -159,6 +154,13 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         if (bits > rem) bits = rem;
         if (bits < 1) bits = 1;
     }
+    return bits;
+}
+
+// the plan's counters of one node into `ctr` (global or LDS)
+__device__ __forceinline__ void plan_account(const Node &nd, int bits, LevelCounters *ctr)
+{
+    const int rem = (int)(nd.meta & 0xff);
     // (fixed addresses, so that the compiler folds each into one atomic per wave)
     const bool sorts = bits == 0 && nd.len > 0 && rem > 0 && !(nd.meta & NODE_TERMINAL);
     if (sorts && nd.len > (u32)LEAF_CAP_SMALL)
@@ -167,14 +169,73 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
         atomicAdd(&ctr->n_small, 1u);
     if (sorts && nd.len <= (u32)LEAF_CAP_TINY)
         atomicAdd(&ctr->n_tiny, 1u);
-    nodes[i].split = (u32)bits;
-    outc[i] = bits ? (1u << bits) : 1u;
-    nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
     if (bits) {
         atomicMax(&ctr->max_bits, (u32)bits);
         atomicAdd(&ctr->n_split, 1u);
         if (bits < rem)
             atomicAdd(&ctr->n_scatter, 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32 n_nodes, int level,
+                                                   u32 chunk_len, u32 *__restrict__ outc,
+                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes)
+        return;
+    const Node nd = nodes[i];
+    const int bits = plan_bits(nd, level, level >= 2 ? ctr->n_over : 0u, l1_cap);
+    plan_account(nd, bits, ctr);
+    nodes[i].split = (u32)bits;
+    outc[i] = bits ? (1u << bits) : 1u;
+    nch[i] = bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
+}
+
+// Levels of at most 1024 nodes (the root, level 1, every level of the record engine's begin): the plan, both exclusive
+// scans (children and chunks per node) and the level's counters in ONE launch of one workgroup -- instead of a memset,
+// the plan and two three-kernel scans (~45 us of launches per level; a count at 100 Mbase has three such levels).
+__global__ __launch_bounds__(1024) void plan_small_kernel(Node *__restrict__ nodes, u32 n_nodes, int level, u32 chunk_len,
+                                                          u32 *__restrict__ outc, u32 *__restrict__ nch,
+                                                          LevelCounters *__restrict__ ctr, int l1_cap)
+{
+    __shared__ LevelCounters lc;
+    __shared__ u32 sa[1024], sb[1024], wtmp[16];
+    const u32 i = threadIdx.x;
+    if (i == 0) {
+        lc.n_next = lc.n_chunks = lc.n_split = lc.n_scatter = lc.max_bits = 0;
+        lc.n_big = lc.n_small = lc.n_tiny = lc.n_over = 0;
+    }
+    __syncthreads();
+    Node nd;
+    nd.len = 0;
+    nd.meta = 0;
+    if (i < n_nodes)
+        nd = nodes[i];
+    if (level >= 2) {
+        if (i < n_nodes && nd.len > (u32)LEAF_CAP && (nd.meta & 0xff) > 0 && !(nd.meta & NODE_TERMINAL))
+            atomicAdd(&lc.n_over, 1u);
+        __syncthreads();
+    }
+    int bits = 0;
+    if (i < n_nodes) {
+        bits = plan_bits(nd, level, lc.n_over, l1_cap);
+        plan_account(nd, bits, &lc);
+        nodes[i].split = (u32)bits;
+    }
+    sa[i] = i < n_nodes ? (bits ? (1u << bits) : 1u) : 0u;
+    sb[i] = i < n_nodes && bits ? (nd.len + chunk_len - 1) / chunk_len : 0u;
+    __syncthreads();
+    const u32 ta = block_scan_inplace<1024>(sa, 1024, wtmp);
+    const u32 tb = block_scan_inplace<1024>(sb, 1024, wtmp);
+    if (i < n_nodes) {
+        outc[i] = sa[i];
+        nch[i] = sb[i];
+    }
+    if (i == 0) {
+        lc.n_next = ta;
+        lc.n_chunks = tb;
+        *ctr = lc;
     }
 }
 
@@ -193,6 +254,27 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
                        chunk_len, outc, nch, ctr, l1_cap);
     return hipGetLastError();
+}
+
+// The whole planning step of a level: counters zeroed, every node planned, outc / nch turned into exclusive scans with
+// their totals in ctr->n_next / ctr->n_chunks.  scan_tmp: scan_tmp_words(n_nodes) words.
+hipError_t launch_plan_level(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch, u32 *scan_tmp,
+                             LevelCounters *ctr, hipStream_t s)
+{
+    if (n_nodes > 0 && n_nodes <= 1024) {
+        static int l1_cap = 0;
+        if (l1_cap == 0) {
+            const char *e = diag_env("DNAGPU_L1_BITS");
+            l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
+        }
+        hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, s, nodes, n_nodes, level, chunk_len, outc, nch, ctr, l1_cap);
+        return hipGetLastError();
+    }
+    hipError_t e = hipMemsetAsync(ctr, 0, sizeof(LevelCounters), s);
+    if (e == hipSuccess) e = launch_plan(nodes, n_nodes, level, chunk_len, outc, nch, ctr, s);
+    if (e == hipSuccess) e = launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, s);
+    if (e == hipSuccess) e = launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, s);
+    return e;
 }
 
 // (nodes and nodes_rw are the same array: no __restrict__ on them)

@@ -1268,11 +1268,8 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         RC_TRY(ps.alloc(n_nodes, &nch));
         RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
         RC_TRY(ps.alloc(1, &ctr));
-        HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(LevelCounters), st));
-        HIP_TRY(launch_plan(cur, n_nodes, (force_bits > 0 && level == 0) ? -force_bits : level, chunk_len, outc, nch,
-                            ctr, st));
-        HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
-        HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
+        HIP_TRY(launch_plan_level(cur, n_nodes, (force_bits > 0 && level == 0) ? -force_bits : level, chunk_len, outc, nch,
+                                  scan_tmp, ctr, st));
         LevelCounters hc;
         RC_TRY(read_back(ctx, &hc, ctr, sizeof hc));
         if (hc.n_split == 0) {
@@ -1395,10 +1392,7 @@ static int sk_level_begin(dnagpu_ctx *ctx, PoolScope &ps, Node *cur, u32 n_nodes
     RC_TRY(ps.alloc(n_nodes, &nch));
     RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
     RC_TRY(ps.alloc(1, &ctr));
-    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(LevelCounters), st));
-    HIP_TRY(launch_plan(cur, n_nodes, -bits, chunk_len, outc, nch, ctr, st));
-    HIP_TRY(launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, st));
-    HIP_TRY(launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, st));
+    HIP_TRY(launch_plan_level(cur, n_nodes, -bits, chunk_len, outc, nch, scan_tmp, ctr, st));
     LevelCounters hc;
     RC_TRY(read_back(ctx, &hc, ctr, sizeof hc));
     lv->n_next = hc.n_next;

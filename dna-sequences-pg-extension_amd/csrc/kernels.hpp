@@ -94,6 +94,9 @@ struct LevelCounters {  // read back by the host once per level
 
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
                        LevelCounters *ctr, hipStream_t s);
+// plan + both scans + counters of a level (one launch for levels of at most 1024 nodes)
+hipError_t launch_plan_level(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch, u32 *scan_tmp,
+                             LevelCounters *ctr, hipStream_t s);
 hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, const u32 *child_base,
                               const u32 *chunk_base, Node *nodes_rw, Chunk *chunks, hipStream_t s);
 // src_dna != 0: the (single) node being split is the root over the packed sequence; flt_lo/flt_span:
