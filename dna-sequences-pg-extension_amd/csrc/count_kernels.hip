@@ -545,16 +545,28 @@ template <int DIG>
 __global__ __launch_bounds__(1024) void level_prefix_kernel(int n_slices, const Node *__restrict__ nodes,
                                                            const Chunk *__restrict__ chunks, u32 n_chunks,
                                                            u32 chunk_len, u32 *__restrict__ hist,
-                                                           u32 *__restrict__ tot)
+                                                           u32 *__restrict__ tot, u32 n_by_node)
 {
     __shared__ u32 part[1024 / DIG][DIG];
-    const u32 c0 = blockIdx.x;
-    if (c0 >= n_chunks)
-        return;
-    const Chunk ch = chunks[c0];
-    if (ch.off != 0)
-        return;                                   // not the node's first chunk
-    const Node nd = nodes[ch.node];
+    // blockIdx.x = a chunk (only a node's first chunk works), or -- n_by_node > 0: levels of few nodes with many chunks
+    // each, where most of a chunk-indexed grid would only look and leave -- a node
+    u32 c0 = blockIdx.x;
+    Node nd;
+    if (n_by_node) {
+        if (c0 >= n_by_node)
+            return;
+        nd = nodes[c0];
+        if (nd.split == 0 || nd.len == 0)
+            return;
+        c0 = nd.chunk_base;
+    } else {
+        if (c0 >= n_chunks)
+            return;
+        const Chunk ch = chunks[c0];
+        if (ch.off != 0)
+            return;                               // not the node's first chunk
+        nd = nodes[ch.node];
+    }
     const u32 R = 1u << nd.split;
     const u32 dl = threadIdx.x % DIG;
     const u32 d = blockIdx.y * DIG + dl;
@@ -716,19 +728,20 @@ hipError_t launch_level_children(Node *nodes, u32 n_nodes, u32 *hist, Node *next
 }
 
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
-                               u32 *hist, u32 *tot, hipStream_t s)
+                               u32 *hist, u32 *tot, hipStream_t s, u32 n_nodes)
 {
     if (n_chunks == 0)
         return hipSuccess;
     // few nodes with many chunks each (the dna root): 64 chunk slices of 16 digits; else 64 digits x 16 or 4 slices
     if (n_split_nodes == 1 && n_chunks > 512) {       // (one split node: its chunks are all the chunks, the first is chunk 0)
         hipLaunchKernelGGL(level_prefix_kernel<16>, dim3(1, ROW_STRIDE / 16), dim3(1024), 0, s, 64, nodes, chunks, n_chunks,
-                           chunk_len, hist, tot);
+                           chunk_len, hist, tot, 0u);
         return hipGetLastError();
     }
     const int slices = n_split_nodes > 0 && n_chunks / n_split_nodes > 32 ? PF_SLICES : 4;
-    hipLaunchKernelGGL(level_prefix_kernel<64>, dim3(n_chunks, ROW_STRIDE / 64), dim3(64 * slices), 0, s, slices, nodes, chunks,
-                       n_chunks, chunk_len, hist, tot);
+    const u32 by_node = n_nodes > 0 && n_nodes * 4 <= n_chunks ? n_nodes : 0u;      // (the record engine's level 1: 256 nodes, 4 K chunks)
+    hipLaunchKernelGGL(level_prefix_kernel<64>, dim3(by_node ? by_node : n_chunks, ROW_STRIDE / 64), dim3(64 * slices), 0, s, slices,
+                       nodes, chunks, n_chunks, chunk_len, hist, tot, by_node);
     return hipGetLastError();
 }
 

@@ -1305,7 +1305,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
                                   dna ? dna->n_words : 0, first, k, buf0, buf1, hist, src_dna ? flt_lo : 0u,
                                   src_dna ? flt_span : ~0u, src_dna ? flt_tb : 0u, vary, level >= 2 ? 1 : 0, stat_min_len, st));
         prof_mark(ctx, LEVEL_PREFIX_NAMES[li]);
-        HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st));
+        HIP_TRY(launch_level_prefix(cur, chunks, hc.n_chunks, hc.n_split, chunk_len, hist, tot, st, n_nodes));
         HIP_TRY(launch_level_children(cur, n_nodes, tot, next, vary, buf0, buf1, stat_min_len, st));
         if (src_dna) {
             // the dna root's children say how many keys survive the owner filter
@@ -1518,7 +1518,7 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     prof_mark(ctx, "sk_hist1");
     HIP_TRY(launch_sk_hist1(l0.next, l1.chunks, l1.n_chunks, rec0, l1.hist, kcount, st));
     prof_mark(ctx, "sk_prefix1");
-    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st));
+    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st, n_coarse));
     HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
     // ---- skew check on the k-mers per mid bucket, before their records move (the list is short: host)
     std::vector<u32> kc(l1.n_next), rcn(l1.n_next);
@@ -1607,7 +1607,7 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
             RC_TRY(ps.alloc(std::max<u32>(lh.n_next, 1), &kcount2));
             HIP_TRY(hipMemsetAsync(kcount2, 0, (size_t)std::max<u32>(lh.n_next, 1) * sizeof(u32), st));
             HIP_TRY(launch_sk_hist1(hnodes, lh.chunks, lh.n_chunks, rec1, lh.hist, kcount2, st, true));
-            HIP_TRY(launch_level_prefix(hnodes, lh.chunks, lh.n_chunks, nh, (u32)chunk_h, lh.hist, lh.tot, st));
+            HIP_TRY(launch_level_prefix(hnodes, lh.chunks, lh.n_chunks, nh, (u32)chunk_h, lh.hist, lh.tot, st, nh));
             HIP_TRY(launch_level_children(hnodes, nh, lh.tot, lh.next, nullptr, nullptr, nullptr, 0, st));
             HIP_TRY(launch_sk_scatter1(hnodes, lh.chunks, lh.n_chunks, rec1, rec0, lh.hist, lh.tot, st, true));
             heavy->total = 0;                    // (nothing is left for the expansion of mid buckets)
@@ -1747,16 +1747,23 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     RC_TRY(ps.alloc((size_t)n_fin, &f_small));
     RC_TRY(ps.alloc((size_t)n_fin, &f_big));
     RC_TRY(ps.alloc((size_t)n_fin, &k_range));
-    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_fin), &scan_tmp));
+    RC_TRY(ps.alloc((size_t)scan_tmp_words(n_fin) * 4, &scan_tmp));      // (four scans at a time: launch_scan_u32_multi)
     RC_TRY(ps.alloc(8, &totals));
     RC_TRY(ps.alloc((size_t)n_fin, &list_small));
     RC_TRY(ps.alloc((size_t)n_fin, &off_small));
     RC_TRY(ps.alloc((size_t)n_fin, &f_over));       // (first: the k-mers of the big buckets, summed)
     HIP_TRY(launch_sk_select_flags(fin, n_fin, cap, big_limit, f_small, f_big, k_range, f_over, st));
-    HIP_TRY(launch_scan_u32(f_small, f_small, n_fin, scan_tmp, totals + 0, st));
-    HIP_TRY(launch_scan_u32(f_big, f_big, n_fin, scan_tmp, totals + 1, st));
-    HIP_TRY(launch_scan_u32(k_range, k_range, n_fin, scan_tmp, totals + 2, st));
-    HIP_TRY(launch_scan_u32(f_over, f_over, n_fin, scan_tmp, totals + 3, st));
+    {
+        ScanSet ss;
+        u32 *arr[4] = {f_small, f_big, k_range, f_over};
+        for (int a = 0; a < 4; a++) {
+            ss.in[a] = arr[a];
+            ss.out[a] = arr[a];
+            ss.total[a] = totals + a;
+        }
+        ss.tmp = scan_tmp;
+        HIP_TRY(launch_scan_u32_multi(ss, 4, n_fin, st));
+    }
     u32 ht[4] = {0, 0, 0, 0};
     RC_TRY(read_back(ctx, ht, totals, sizeof ht));
     const u32 n_small = ht[0], n_big = ht[1];
@@ -1819,8 +1826,18 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     RC_TRY(ps.alloc((size_t)n_fin, &f_over_raw));
     RC_TRY(ps.alloc((size_t)n_fin, &k_over));
     HIP_TRY(launch_sk_over_flags(fin, n_fin, cap, big_limit, f_big, big_status, f_over_raw, k_over, st));
-    HIP_TRY(launch_scan_u32(f_over_raw, f_over, n_fin, scan_tmp, totals + 4, st));
-    HIP_TRY(launch_scan_u32(k_over, k_over, n_fin, scan_tmp, totals + 5, st));
+    {
+        ScanSet ss;
+        memset(&ss, 0, sizeof ss);
+        ss.in[0] = f_over_raw;
+        ss.out[0] = f_over;
+        ss.total[0] = totals + 4;
+        ss.in[1] = k_over;
+        ss.out[1] = k_over;
+        ss.total[1] = totals + 5;
+        ss.tmp = scan_tmp;
+        HIP_TRY(launch_scan_u32_multi(ss, 2, n_fin, st));
+    }
     u32 ho[2] = {0, 0};
     RC_TRY(read_back(ctx, ho, totals + 4, sizeof ho));
     const u32 n_over = ho[0];

@@ -452,6 +452,118 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const u32 *in, u
     }
 }
 
+// up to four scans of the same length in the three launches of one (blockIdx.y = which array): the selections of the
+// record engine scan four flag / size arrays over the final buckets back to back
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_multi_kernel(ScanSet set, u64 n, u64 tmp_stride)
+{
+    __shared__ u32 sh4[4];
+    const u32 *in = set.in[blockIdx.y];
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++)
+        if (base + q < n)
+            v += in[base + q];
+    u32 r = block_reduce_256(v, sh4);
+    if (threadIdx.x == 0)
+        set.tmp[blockIdx.y * tmp_stride + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_multi_kernel(ScanSet set, u64 nb, u64 tmp_stride)
+{
+    __shared__ u32 wtot[16];
+    __shared__ u32 carry_sh;
+    u32 *sums = set.tmp + blockIdx.y * tmp_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_sh = 0;
+    __syncthreads();
+    for (u64 b0 = 0; b0 < nb; b0 += 1024) {
+        u64 i = b0 + threadIdx.x;
+        u32 v = i < nb ? sums[i] : 0, inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 t = __shfl_up(inc, off);
+            if (lane >= off)
+                inc += t;
+        }
+        if (lane == 63)
+            wtot[wave] = inc;
+        __syncthreads();
+        u32 wbase = 0, all = 0;
+        for (int w = 0; w < 16; w++) {
+            u32 t = wtot[w];
+            if (w < wave)
+                wbase += t;
+            all += t;
+        }
+        u32 carry = carry_sh;
+        if (i < nb)
+            sums[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry_sh = carry + all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && set.total[blockIdx.y])
+        *set.total[blockIdx.y] = carry_sh;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_multi_kernel(ScanSet set, u64 n, u64 tmp_stride)
+{
+    __shared__ u32 wtot[4];
+    const u32 *in = set.in[blockIdx.y];          // (in == out allowed: every value of a thread's eight is loaded first)
+    u32 *out = set.out[blockIdx.y];
+    const u32 *sums = set.tmp + blockIdx.y * tmp_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 sum = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        v[q] = (base + q < n) ? in[base + q] : 0;
+        sum += v[q];
+    }
+    u32 inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(inc, off);
+        if (lane >= off)
+            inc += t;
+    }
+    if (lane == 63)
+        wtot[wave] = inc;
+    __syncthreads();
+    u32 wbase = 0;
+    for (int w = 0; w < wave; w++)
+        wbase += wtot[w];
+    u32 run = sums[blockIdx.x] + wbase + inc - sum;
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; q++) {
+        if (base + q < n)
+            out[base + q] = run;
+        run += v[q];
+    }
+}
+
+hipError_t launch_scan_u32_multi(const ScanSet &set, int n_arrays, u64 n, hipStream_t s)
+{
+    if (n_arrays < 1 || n_arrays > 4)
+        return hipErrorInvalidValue;
+    if (n == 0) {
+        for (int a = 0; a < n_arrays; a++)
+            if (set.total[a]) {
+                const hipError_t e = hipMemsetAsync(set.total[a], 0, sizeof(u32), s);
+                if (e != hipSuccess)
+                    return e;
+            }
+        return hipSuccess;
+    }
+    const u64 nb = (n + SCAN_TILE - 1) / SCAN_TILE, stride = scan_tmp_words(n);
+    hipLaunchKernelGGL(scan_reduce_multi_kernel, dim3((unsigned)nb, (unsigned)n_arrays), dim3(SCAN_BLOCK), 0, s, set, n, stride);
+    hipLaunchKernelGGL(scan_sums_multi_kernel, dim3(1, (unsigned)n_arrays), dim3(1024), 0, s, set, nb, stride);
+    hipLaunchKernelGGL(scan_apply_multi_kernel, dim3((unsigned)nb, (unsigned)n_arrays), dim3(SCAN_BLOCK), 0, s, set, n, stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total, hipStream_t s)
 {
     if (n == 0) {

@@ -43,6 +43,15 @@ hipError_t launch_wire_swap(const u64 *src, u64 *dst, u64 n_words, u64 last_mask
 // exclusive scan of n u32 values (in != out allowed, in == out allowed); *total receives the sum.
 // tmp must hold scan_tmp_words(n) u32 values.
 u64 scan_tmp_words(u64 n);
+// up to four exclusive scans of the same length n in three launches: in[a] -> out[a] (in == out allowed), *total[a] = the
+// sum (may be null); tmp holds n_arrays x scan_tmp_words(n) words
+struct ScanSet {
+    const u32 *in[4];
+    u32 *out[4];
+    u32 *total[4];
+    u32 *tmp;
+};
+hipError_t launch_scan_u32_multi(const ScanSet &set, int n_arrays, u64 n, hipStream_t s);
 hipError_t launch_scan_u32(const u32 *in, u32 *out, u64 n, u32 *tmp, u32 *total, hipStream_t s);
 
 // ---------------------------------------------------------------- count_kernels.hip
@@ -109,7 +118,7 @@ hipError_t launch_level_hist(const Node *nodes, const Chunk *chunks, u32 n_chunk
 // per split node and 64-digit group: chunk rows -> exclusive prefixes over chunks; per-digit totals
 // into tot[row of the node's first chunk]
 hipError_t launch_level_prefix(const Node *nodes, const Chunk *chunks, u32 n_chunks, u32 n_split_nodes, u32 chunk_len,
-                               u32 *hist, u32 *tot, hipStream_t s);
+                               u32 *hist, u32 *tot, hipStream_t s, u32 n_nodes = 0);
 // per node: leaf -> copied to the next list; split -> totals scanned over digits, children appended
 // in digit (= key) order, tot row overwritten with each digit's absolute base
 // vary (may be null): per node NODE_STAT_WORDS words -- the number of low key bits that vary inside it, keys below /
