@@ -217,7 +217,11 @@ template <int W>
 __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
 {
     const int lane = threadIdx.x & 63;
-    const u32 r0 = (u32)lane * 32;
+    // (opaque to the compiler: else the 32 row numbers r0 + j -- and, where they are widened, their 64-bit forms -- are
+    // hoisted out of the callers' tile loops as loop invariants and spilled: sk_scatter0 carried 22 spilled VGPRs and
+    // 92 bytes of scratch per lane for them, 0.4 ms of its 3.9 at 3 Gbase)
+    u32 r0 = (u32)lane * 32;
+    asm volatile("" : "+v"(r0));
     u32 lb = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -239,7 +243,8 @@ __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
 template <int W, typename Emit>
 __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
-    const u32 r0 = (u32)(threadIdx.x & 63) * 32;
+    u32 r0 = (u32)(threadIdx.x & 63) * 32;
+    asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -260,7 +265,8 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Em
 template <int W, typename Emit>
 __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
-    const u32 r0 = (u32)(threadIdx.x & 63) * 32;
+    u32 r0 = (u32)(threadIdx.x & 63) * 32;
+    asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
