@@ -1955,11 +1955,20 @@ constexpr u64 SK_MIN_ROWS = (u64)1 << 25;
 // the engine pays once the runs are long enough (mean (k - 13) / 2 k-mers per record) and the sequence is: measured at
 // 1 Gbase, tree vs this engine: k = 23 13.4 vs 13.1 ms, 24 13.2 vs 12.4, 25 13.2 vs 12.0, 27 13.2 vs 11.5, 29 13.0 vs 10.8;
 // k = 31: 16 Mbase 0.63 vs 0.63 ms, 64 Mbase 1.32 vs 1.11, 250 Mbase 3.70 vs 3.21, 3 Gbase 42.0 vs 30.5
-// k = 21 and 22 (13-base minimizers: runs of 5 - 5.5 k-mers) are supported by the engine -- the multi-GPU record exchange
-// uses it from k = 21 -- but on one GPU they gain too little to be the default (tools/engine_probe.py, tree vs records:
-// k = 21 1.64 vs 1.58 ms at 100 Mbase, 13.1 vs 13.2 at 1 Gbase, 42.2 vs 44.7 at 3 Gbase; k = 22 1.62 vs 1.50, 13.1 vs 12.2,
-// 42.1 vs 43.4; k = 23 1.62 vs 1.43, 13.0 vs 11.7, 42.1 vs 36.8)
+// k = 21 and 22 (13-base minimizers: runs of 5 - 5.5 k-mers; the multi-GPU record exchange uses the engine from k = 21
+// whatever the size) gain less, and lose on the longest sequences, where the tree's passes run at their best
+// (tools/engine_probe.py, tree vs records: k = 21 0.93 vs 0.91 ms at 50 Mbase, 1.64 vs 1.58 at 100 Mbase, 3.53 vs 3.34 at
+// 250 Mbase, 13.1 vs 13.2 at 1 Gbase, 42.2 vs 44.7 at 3 Gbase; k = 22 0.90 vs 0.86, 1.62 vs 1.50, 3.52 vs 3.12, 13.1 vs 12.2,
+// 42.1 vs 43.4; k = 23 1.62 vs 1.43, 13.0 vs 11.7, 42.1 vs 36.8): they take the engine up to 2^29 (k = 21) and 2^31 (k = 22) rows
 constexpr int SK_MIN_K = 23;
+static bool sk_is_default(u64 n, int k)
+{
+    if (n < SK_MIN_ROWS)
+        return false;
+    if (k >= SK_MIN_K)
+        return true;
+    return (k == 22 && n <= ((u64)1 << 31)) || (k == 21 && n <= ((u64)1 << 29));
+}
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,
                       bool any_order = false)
@@ -1976,7 +1985,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     prof_begin(ctx);
     int rc;
     const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && n >= 64;
-    if (any_order && dna && fixed_bits == 0 && n_owners == 1 && ((k >= SK_MIN_K && n >= SK_MIN_ROWS) || force_sk)) {
+    if (any_order && dna && fixed_bits == 0 && n_owners == 1 && (sk_is_default(n, k) || force_sk)) {
         rc = count_sk(ctx, dna, first, n, k, h);
         if (rc != DNAGPU_SK_SKEWED) {
             prof_end(ctx);

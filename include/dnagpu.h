@@ -175,8 +175,9 @@ typedef struct dnagpu_hist dnagpu_hist;
 int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                        uint64_t first, uint64_t count, dnagpu_hist **out);
 /* The same groups when the caller does not need them in key order -- PostgreSQL's own GROUP BY order is
- * unspecified (test.sql:95-104), so this is what the SQL entry point calls.  Long k-mers (k >= 23) of long
- * sequences are then partitioned as super-k-mers (runs of consecutive k-mers sharing a minimizer, 16 bytes per
+ * unspecified (test.sql:95-104), so this is what the SQL entry point calls.  Long k-mers (k >= 21) of long
+ * sequences (2^25 rows or more; k = 21 and 22: where that is the faster engine, up to 2^29 / 2^31 rows) are then
+ * partitioned as super-k-mers (runs of consecutive k-mers sharing a minimizer, 16 bytes per
  * ~9 k-mers) instead of 8-byte keys: less than a third of the partition traffic.  dnagpu_hist_download and
  * dnagpu_hist_sorted_view then serve the groups bucket by bucket (keys ascending inside a bucket only);
  * dnagpu_hist_is_sorted tells which kind a histogram is. */
