@@ -1149,20 +1149,26 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                 w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
             const u32 hmask = (u32)(kmask >> 32);                // (k >= 21: the low dword is whole)
             const u32 id0 = (u32)tid << 2;
+            // all four keys of the quad first, straight into the registers that keep them (the window moves on two bits per
+            // k-mer whether the position exists or not: no copies where the branches of the inserts meet)
+#pragma unroll
+            for (int q = 0; q < SKC_KPT; q++) {
+                ckl[q] = w0;
+                ckh[q] = w1 & hmask;
+                w0 = __builtin_amdgcn_alignbit(w1, w0, 2);
+                w1 = __builtin_amdgcn_alignbit(w2, w1, 2);
+                w2 >>= 2;
+            }
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
                 if (j0 + (u32)q < rl) {
-                    const u32 kl = w0, kh = w1 & hmask;
-                    w0 = __builtin_amdgcn_alignbit(w1, w0, 2);
-                    w1 = __builtin_amdgcn_alignbit(w2, w1, 2);
-                    w2 >>= 2;
-                    ckl[q] = kl;
-                    ckh[q] = kh;
+                    const u32 kl = ckl[q], kh = ckh[q];
                     if (SK_DBG(32)) {
                         c_mask |= (kl & 1) ? 1u << q : 0u;
                     } else {
                         const u32 x = (kl ^ kh) * 0x9E3779B1u;
-                        u32 sa = ((u32)__umul24(x >> 16, (u32)SKC_SLOTS) >> 16) << 2;        // byte address of the home slot
+                        u32 &sa = cslot[q];                      // byte address of the probed slot: where a claim leaves it, it stays
+                        sa = ((u32)__umul24(x >> 16, (u32)SKC_SLOTS) >> 16) << 2;
                         const u32 y = x ^ (x >> 15);             // (the product's low bits alone depend on the key's low bits only)
                         // 19 bits of fingerprint under a clear top bit: no word equals the all-ones of a free slot
                         const u32 word = ((y & 0x7FFFFu) << 12) | id0 | (u32)q;
@@ -1170,7 +1176,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                             const u32 old = atomicCAS(reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + sa), SKC_FREE, word);
                             if (old == SKC_FREE) {
                                 c_mask |= 1u << q;
-                                cslot[q] = sa;
                                 break;
                             }
                             if ((old ^ word) < 4096u) {
