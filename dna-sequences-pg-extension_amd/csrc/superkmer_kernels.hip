@@ -487,7 +487,20 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
     }
     __syncthreads();
     const u64 *hi = reinterpret_cast<const u64 *>(recs + (u64)nd.start + ch.off) + 1;
-    for (u32 i = threadIdx.x; i < ch.len; i += SK1_NT) {
+    u32 i = threadIdx.x;
+    for (; i + 3u * SK1_NT < ch.len; i += 4u * SK1_NT) {           // four loads in flight per thread
+        u64 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            m[j] = __builtin_nontemporal_load(&hi[(u64)(i + (u32)j * SK1_NT) * 2]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 d1 = (u32)(m[j] >> shift) & (R - 1);
+            atomicAdd(&h[d1], 1u);
+            atomicAdd(&kc[d1], (u32)((m[j] >> 44) & 31) + 1u);
+        }
+    }
+    for (; i < ch.len; i += SK1_NT) {
         const u64 m = __builtin_nontemporal_load(&hi[(u64)i * 2]);
         const u32 d1 = (u32)(m >> shift) & (R - 1);
         atomicAdd(&h[d1], 1u);
@@ -526,21 +539,37 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     for (u32 d = tid; d < R; d += SK1_NT)
         gpos[d] = trow[d] + hrow[d];
     const ull2_t *src = src_all + (u64)nd.start + ch.off;
+    const u32 dmask = R - 1;
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
+        const bool full = n_tile == (u32)SK1_TILE;     // (all tiles of a chunk but its last)
         for (u32 d = tid; d < R; d += SK1_NT)
             cnt[d] = 0;
         __syncthreads();
+        // A full tile's loads carry no bounds test: all eight of a thread are in flight together (behind a test each the
+        // compiler waited for one load before it issued the next -- one KB per wave in flight, the kernel's whole bound).
         u32 dig[SK1_ITEMS], rank[SK1_ITEMS];
+        if (full) {
+            u64 m[SK1_ITEMS];
 #pragma unroll
-        for (int j = 0; j < SK1_ITEMS; j++) {
-            const u32 i = tid + j * SK1_NT;
-            dig[j] = 0;
-            rank[j] = 0;
-            if (i < n_tile) {
-                const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
-                dig[j] = (u32)(m >> shift) & (R - 1);
+            for (int j = 0; j < SK1_ITEMS; j++)
+                m[j] = reinterpret_cast<const u64 *>(src + t0 + tid + j * SK1_NT)[1];
+#pragma unroll
+            for (int j = 0; j < SK1_ITEMS; j++) {
+                dig[j] = (u32)(m[j] >> shift) & dmask;
                 rank[j] = atomicAdd(&cnt[dig[j]], 1u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SK1_ITEMS; j++) {
+                const u32 i = tid + j * SK1_NT;
+                dig[j] = 0;
+                rank[j] = 0;
+                if (i < n_tile) {
+                    const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
+                    dig[j] = (u32)(m >> shift) & dmask;
+                    rank[j] = atomicAdd(&cnt[dig[j]], 1u);
+                }
             }
         }
         __syncthreads();
@@ -552,13 +581,30 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 idx[cnt[dig[j]] + rank[j]] = (unsigned short)i;
         }
         __syncthreads();
+        if (full) {
+            // two rounds of four records: 16 data registers in flight per thread (the kernel lives on 64)
 #pragma unroll
-        for (int j = 0; j < SK1_ITEMS; j++) {
-            const u32 s = tid + j * SK1_NT;
-            if (s < n_tile) {
-                const ull2_t r = src[t0 + idx[s]];
-                const u32 d = (u32)(r.y >> shift) & (R - 1);
-                __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s - cnt[d])]);
+            for (int h = 0; h < SK1_ITEMS; h += 4) {
+                ull2_t r[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    r[j] = src[t0 + idx[tid + (h + j) * SK1_NT]];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32 sl = tid + (h + j) * SK1_NT;
+                    const u32 d = (u32)(r[j].y >> shift) & dmask;
+                    __builtin_nontemporal_store(r[j], &dst_all[gpos[d] + (sl - cnt[d])]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SK1_ITEMS; j++) {
+                const u32 sl = tid + j * SK1_NT;
+                if (sl < n_tile) {
+                    const ull2_t r = src[t0 + idx[sl]];
+                    const u32 d = (u32)(r.y >> shift) & dmask;
+                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (sl - cnt[d])]);
+                }
             }
         }
         __syncthreads();
@@ -809,16 +855,24 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
     // for the output nodes and ranked for the copy in the same sweep.
     const bool one_tile = nd.len <= (u32)SKR_TILE;
     u32 dig1[SKR_ITEMS], rank1[SKR_ITEMS];
-    if (one_tile) {
+    const u32 last = nd.len ? nd.len - 1u : 0u;
+    if (one_tile && nd.len) {
+        // the loads carry no bounds test (a slot past the end reads the last record again and drops it): all of a thread's
+        // are in flight together -- behind a test each, the compiler waited for one before it issued the next
+        u64 m[SKR_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SKR_ITEMS; j++) {
+            const u32 r = tid + j * SKR_NT;
+            m[j] = reinterpret_cast<const u64 *>(src + (r < nd.len ? r : last))[1];
+        }
 #pragma unroll
         for (int j = 0; j < SKR_ITEMS; j++) {
             const u32 r = tid + j * SKR_NT;
             dig1[j] = 0;
             rank1[j] = 0;
             if (r < nd.len) {
-                const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
-                const u32 d2 = (u32)(m >> 59) & 15u;
-                const u32 len = (u32)((m >> 44) & 31) + 1u;
+                const u32 d2 = (u32)(m[j] >> 59) & 15u;
+                const u32 len = (u32)((m[j] >> 44) & 31) + 1u;
                 atomicAdd(&rc[lane][d2], 1u);
                 atomicAdd(&kc[lane][d2], len);
                 atomicAdd(&qc[lane][d2], (len + 3u) >> 2);
@@ -826,7 +880,7 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
                 rank1[j] = atomicAdd(&tcnt[d2], 1u);
             }
         }
-    } else {
+    } else if (!one_tile) {
         for (u32 r = tid; r < nd.len; r += SKR_NT) {
             const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
             const u32 d2 = (u32)(m >> 59) & 15u;
@@ -879,13 +933,26 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
                 idx[tcnt[dig1[j]] + rank1[j]] = (unsigned short)r;
         }
         __syncthreads();
+        if (nd.len == 0)
+            return;
+        // two rounds of four records in flight per thread (the kernel lives on 64 registers)
 #pragma unroll
-        for (int j = 0; j < SKR_ITEMS; j++) {
-            const u32 s2 = tid + j * SKR_NT;
-            if (s2 < nd.len) {
-                const ull2_t r = src[idx[s2]];
-                const u32 d = (u32)(r.y >> 59) & 15u;
-                __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s2 - tcnt[d])]);
+        for (int h = 0; h < SKR_ITEMS; h += 4) {
+            if ((u32)(h * SKR_NT) >= nd.len)
+                break;
+            ull2_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 s2 = tid + (h + j) * SKR_NT;
+                r[j] = src[idx[s2 < nd.len ? s2 : last]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 s2 = tid + (h + j) * SKR_NT;
+                if (s2 < nd.len) {
+                    const u32 d = (u32)(r[j].y >> 59) & 15u;
+                    __builtin_nontemporal_store(r[j], &dst_all[gpos[d] + (s2 - tcnt[d])]);
+                }
             }
         }
         return;
