@@ -526,11 +526,13 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
 {
     __shared__ u32 cnt[ROW_STRIDE];
     __shared__ u32 gpos[ROW_STRIDE];
-    __shared__ unsigned short idx[SK1_TILE];
+    // a full tile: half of its records at a time, in sorted order (64 KB); a partial tile: the index list (16 KB of it)
+    __shared__ __attribute__((aligned(16))) ull2_t stage[SK1_TILE / 2];
+    unsigned short *idx = reinterpret_cast<unsigned short *>(stage);
     __shared__ u32 wtmp[SK1_NT / 64];
     if (blockIdx.x >= n_chunks)
         return;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const Chunk ch = chunks[blockIdx.x];
     const Node nd = nodes[ch.node];
     const u32 R = 1u << nd.split;
@@ -542,24 +544,47 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     const u32 dmask = R - 1;
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
-        const bool full = n_tile == (u32)SK1_TILE;     // (all tiles of a chunk but its last)
+        asm volatile("" : "+v"(tid));              // (thread-derived addresses recomputed per tile, not held: the kernel lives on 64 registers)
         for (u32 d = tid; d < R; d += SK1_NT)
             cnt[d] = 0;
         __syncthreads();
-        // A full tile's loads carry no bounds test: all eight of a thread are in flight together (behind a test each the
-        // compiler waited for one load before it issued the next -- one KB per wave in flight, the kernel's whole bound).
-        u32 dig[SK1_ITEMS], rank[SK1_ITEMS];
-        if (full) {
-            u64 m[SK1_ITEMS];
+        if (n_tile == (u32)SK1_TILE) {
+            // ---- a full tile (all tiles of a chunk but its last): every record is read ONCE, 16 bytes per lane and all
+            // eight of a thread in flight; it waits in registers while its sorted position in the tile is found, goes
+            // through LDS (half a tile at a time) into sorted order, and leaves in runs -- 16 bytes per lane, consecutive
+            // lanes to consecutive addresses.  (Reading the digits first and gathering the records by index afterwards --
+            // the partial tile's way below -- brings every record in twice: 16 GB moved for 10.7.)
+            ull2_t rec[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++)
-                m[j] = reinterpret_cast<const u64 *>(src + t0 + tid + j * SK1_NT)[1];
+                rec[j] = src[t0 + tid + j * SK1_NT];
+            u32 pos[SK1_ITEMS];
 #pragma unroll
-            for (int j = 0; j < SK1_ITEMS; j++) {
-                dig[j] = (u32)(m[j] >> shift) & dmask;
-                rank[j] = atomicAdd(&cnt[dig[j]], 1u);
+            for (int j = 0; j < SK1_ITEMS; j++)
+                pos[j] = atomicAdd(&cnt[(u32)(rec[j].y >> shift) & dmask], 1u);
+            __syncthreads();
+            block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
+#pragma unroll
+            for (int j = 0; j < SK1_ITEMS; j++)
+                pos[j] += cnt[(u32)(rec[j].y >> shift) & dmask];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int j = 0; j < SK1_ITEMS; j++)
+                    if ((pos[j] >> 12) == (u32)h)
+                        stage[pos[j] & 4095u] = rec[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < SK1_ITEMS / 2; j++) {
+                    const u32 sl = (u32)h * (SK1_TILE / 2) + tid + j * SK1_NT;
+                    const ull2_t r = stage[tid + j * SK1_NT];
+                    const u32 d = (u32)(r.y >> shift) & dmask;
+                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (sl - cnt[d])]);
+                }
+                __syncthreads();
             }
         } else {
+            u32 dig[SK1_ITEMS], rank[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const u32 i = tid + j * SK1_NT;
@@ -571,32 +596,15 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     rank[j] = atomicAdd(&cnt[dig[j]], 1u);
                 }
             }
-        }
-        __syncthreads();
-        block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                     // cnt -> exclusive offsets
+            __syncthreads();
+            block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
 #pragma unroll
-        for (int j = 0; j < SK1_ITEMS; j++) {
-            const u32 i = tid + j * SK1_NT;
-            if (i < n_tile)
-                idx[cnt[dig[j]] + rank[j]] = (unsigned short)i;
-        }
-        __syncthreads();
-        if (full) {
-            // two rounds of four records: 16 data registers in flight per thread (the kernel lives on 64)
-#pragma unroll
-            for (int h = 0; h < SK1_ITEMS; h += 4) {
-                ull2_t r[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    r[j] = src[t0 + idx[tid + (h + j) * SK1_NT]];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const u32 sl = tid + (h + j) * SK1_NT;
-                    const u32 d = (u32)(r[j].y >> shift) & dmask;
-                    __builtin_nontemporal_store(r[j], &dst_all[gpos[d] + (sl - cnt[d])]);
-                }
+            for (int j = 0; j < SK1_ITEMS; j++) {
+                const u32 i = tid + j * SK1_NT;
+                if (i < n_tile)
+                    idx[cnt[dig[j]] + rank[j]] = (unsigned short)i;
             }
-        } else {
+            __syncthreads();
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const u32 sl = tid + j * SK1_NT;
@@ -606,8 +614,8 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     __builtin_nontemporal_store(r, &dst_all[gpos[d] + (sl - cnt[d])]);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         // advance: digit d held (next offset - its offset) records
         for (u32 d = tid; d < R; d += SK1_NT) {
             const u32 end = d + 1 < R ? cnt[d + 1] : n_tile;
@@ -836,7 +844,9 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
 {
     __shared__ u32 rc[64][17], kc[64][17], qc[64][17];   // per-lane copies of the 16 record / k-mer / quad counters
     __shared__ u32 gpos[16], tcnt[17];
-    __shared__ unsigned short idx[SKR_TILE];
+    // a bucket of one tile: half a tile of records at a time, in regrouped order (64 KB); longer buckets: the index list
+    __shared__ __attribute__((aligned(16))) ull2_t stage[SKR_TILE / 2];
+    unsigned short *idx = reinterpret_cast<unsigned short *>(stage);
     const u32 i = blockIdx.x;
     if (i >= n_mids)
         return;
@@ -854,30 +864,30 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
     // A mid bucket of at most one tile (the planned size is ~5,000 records): its digit words are read ONCE -- counted
     // for the output nodes and ranked for the copy in the same sweep.
     const bool one_tile = nd.len <= (u32)SKR_TILE;
-    u32 dig1[SKR_ITEMS], rank1[SKR_ITEMS];
     const u32 last = nd.len ? nd.len - 1u : 0u;
+    // A bucket of one tile reads every record ONCE, 16 bytes per lane, all of a thread's loads in flight (no bounds test:
+    // a slot past the end reads the last record again and drops it); the records wait in registers while they are counted
+    // and ranked, and leave through LDS in regrouped order (as sk_scatter1's full tiles do).
+    ull2_t rec[SKR_ITEMS];
+    u32 pos[SKR_ITEMS];
     if (one_tile && nd.len) {
-        // the loads carry no bounds test (a slot past the end reads the last record again and drops it): all of a thread's
-        // are in flight together -- behind a test each, the compiler waited for one before it issued the next
-        u64 m[SKR_ITEMS];
 #pragma unroll
         for (int j = 0; j < SKR_ITEMS; j++) {
             const u32 r = tid + j * SKR_NT;
-            m[j] = reinterpret_cast<const u64 *>(src + (r < nd.len ? r : last))[1];
+            rec[j] = src[r < nd.len ? r : last];
         }
 #pragma unroll
         for (int j = 0; j < SKR_ITEMS; j++) {
             const u32 r = tid + j * SKR_NT;
-            dig1[j] = 0;
-            rank1[j] = 0;
+            pos[j] = 0;
             if (r < nd.len) {
-                const u32 d2 = (u32)(m[j] >> 59) & 15u;
-                const u32 len = (u32)((m[j] >> 44) & 31) + 1u;
+                const u64 m = rec[j].y;
+                const u32 d2 = (u32)(m >> 59) & 15u;
+                const u32 len = (u32)((m >> 44) & 31) + 1u;
                 atomicAdd(&rc[lane][d2], 1u);
                 atomicAdd(&kc[lane][d2], len);
                 atomicAdd(&qc[lane][d2], (len + 3u) >> 2);
-                dig1[j] = d2;
-                rank1[j] = atomicAdd(&tcnt[d2], 1u);
+                pos[j] = atomicAdd(&tcnt[d2], 1u);
             }
         }
     } else if (!one_tile) {
@@ -926,34 +936,32 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
     }
     __syncthreads();
     if (one_tile) {
-#pragma unroll
-        for (int j = 0; j < SKR_ITEMS; j++) {
-            const u32 r = tid + j * SKR_NT;
-            if (r < nd.len)
-                idx[tcnt[dig1[j]] + rank1[j]] = (unsigned short)r;
-        }
-        __syncthreads();
         if (nd.len == 0)
             return;
-        // two rounds of four records in flight per thread (the kernel lives on 64 registers)
 #pragma unroll
-        for (int h = 0; h < SKR_ITEMS; h += 4) {
-            if ((u32)(h * SKR_NT) >= nd.len)
+        for (int j = 0; j < SKR_ITEMS; j++)
+            pos[j] += tcnt[(u32)(rec[j].y >> 59) & 15u];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((u32)h * (SKR_TILE / 2) >= nd.len)
                 break;
-            ull2_t r[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 s2 = tid + (h + j) * SKR_NT;
-                r[j] = src[idx[s2 < nd.len ? s2 : last]];
+            for (int j = 0; j < SKR_ITEMS; j++) {
+                const u32 r = tid + j * SKR_NT;
+                if (r < nd.len && (pos[j] >> 12) == (u32)h)
+                    stage[pos[j] & 4095u] = rec[j];
             }
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 s2 = tid + (h + j) * SKR_NT;
+            for (int j = 0; j < SKR_ITEMS / 2; j++) {
+                const u32 s2 = (u32)h * (SKR_TILE / 2) + tid + j * SKR_NT;
                 if (s2 < nd.len) {
-                    const u32 d = (u32)(r[j].y >> 59) & 15u;
-                    __builtin_nontemporal_store(r[j], &dst_all[gpos[d] + (s2 - tcnt[d])]);
+                    const ull2_t r = stage[tid + j * SKR_NT];
+                    const u32 d = (u32)(r.y >> 59) & 15u;
+                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s2 - tcnt[d])]);
                 }
             }
+            __syncthreads();
         }
         return;
     }
