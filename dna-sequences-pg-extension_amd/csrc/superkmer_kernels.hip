@@ -579,7 +579,9 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const u32 sl = (u32)h * (SK1_TILE / 2) + tid + j * SK1_NT;
                     const ull2_t r = stage[tid + j * SK1_NT];
                     const u32 d = (u32)(r.y >> shift) & dmask;
-                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (sl - cnt[d])]);
+                    // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
+                    // this workgroup's next tile -- completes them; kept in L2 they merge more often: 3.44 -> 3.30 ms)
+                    dst_all[gpos[d] + (sl - cnt[d])] = r;
                 }
                 __syncthreads();
             }
