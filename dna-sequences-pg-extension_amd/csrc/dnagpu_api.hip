@@ -1573,7 +1573,12 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
     ps.ptrs.push_back(rec1);
     prof_mark(ctx, "sk_scatter1");
-    HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st));
+    {   // the mid buckets' cursors start at their exact bases (the prefix of the histogram); tiles reserve their slots there
+        u32 *gcur = nullptr;
+        RC_TRY(ps.alloc((size_t)std::max<u32>(l1.n_chunks, 1) * ROW_STRIDE, &gcur));
+        HIP_TRY(hipMemcpyAsync(gcur, l1.tot, (size_t)std::max<u32>(l1.n_chunks, 1) * ROW_STRIDE * sizeof(u32), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st, false, gcur));
+    }
 
     const u32 nh = (u32)heavy_idx.size();
     const bool heavy_expand = (ctx->debug_flags & DNAGPU_DEBUG_HEAVY_EXPAND) != 0;

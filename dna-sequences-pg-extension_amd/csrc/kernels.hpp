@@ -172,7 +172,7 @@ hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, con
 hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
                            hipStream_t s, bool by_d2 = false);
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
-                              const u32 *tot, hipStream_t s, bool by_d2 = false);
+                              const u32 *tot, hipStream_t s, bool by_d2 = false, u32 *gcur = nullptr);
 // (by_d2: the same kernels on the 4-bit digit d2 -- the heavy mid buckets' split into final buckets)
 hipError_t launch_sk_heavy_finals(const Node *kids, u32 n, const u32 *kcount, Node *out, hipStream_t s);
 // buckets sk_count does not take, expanded to keys in record order (no host step): slices of sk_flat_slice() records
