@@ -14,6 +14,8 @@ from .binding import (  # noqa: F401
     DEBUG_FORCE_SUPERKMER,
     DEBUG_GUARD_POOL,
     DEBUG_HEAVY_EXPAND,
+    DEBUG_NO_SPEC1,
+    DEBUG_SPEC1_OVERFLOW,
     Context,
     Dna,
     DnaGpuError,

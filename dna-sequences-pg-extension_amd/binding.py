@@ -24,6 +24,8 @@ DEBUG_POISON_POOL = 1
 DEBUG_FORCE_SUPERKMER = 2
 DEBUG_HEAVY_EXPAND = 4
 DEBUG_GUARD_POOL = 8
+DEBUG_NO_SPEC1 = 16
+DEBUG_SPEC1_OVERFLOW = 32
 
 
 def _env_debug():

@@ -1447,8 +1447,10 @@ static SkGeom sk_geometry(const dnagpu_ctx *ctx, u64 n, int k)
 // Level 0: rows [first, first + n) of the packed sequence -> records in the coarse buckets of geometry g.
 // *rec0 = the record buffer (pool memory of ps), *coarse / *n_coarse = the 2^r0bits coarse nodes (device; start / len in
 // records, in digit order), kids = the same on the host.
+// (rec0_cap != null: the buffer is made large enough for the regions of a speculative level 1 -- sk_levels12 -- and
+// *rec0_cap = the records it holds)
 static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, const SkGeom &g, void **rec0_out,
-                     Node **coarse, u32 *n_coarse, std::vector<Node> *kids_out, u64 *n_recs_out)
+                     Node **coarse, u32 *n_coarse, std::vector<Node> *kids_out, u64 *n_recs_out, u64 *rec0_cap = nullptr)
 {
     hipStream_t st = ctx->stream;
     const int b1 = g.b1, r0bits = g.r0bits;
@@ -1481,7 +1483,16 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     if (n_recs > 0xFFFFFFFFull)
         return DNAGPU_ERR_TOO_LARGE;
     void *rec0 = nullptr;
-    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec0));
+    u64 cap = std::max<u64>(n_recs, 1);
+    if (rec0_cap) {
+        u64 span = 0;
+        for (const Node &c : kids)
+            span += sk_spec_span(c.len, b1);
+        if (span <= 0xFFFFFFFFull)
+            cap = std::max(cap, span);
+        *rec0_cap = cap;
+    }
+    RC_TRY(pool_alloc(ctx, (size_t)cap * 16, &rec0));
     ps.ptrs.push_back(rec0);
     prof_mark(ctx, "sk_scatter0");
     HIP_TRY(launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
@@ -1495,8 +1506,13 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
 
 // Levels 1 and 2 over coarse nodes (records of rec0, which this takes over).  n = the k-mers the records must hold
 // (0 = not known: records received from other ranks).  On success *n_kmers = the k-mers found.
+// host_lens / rec0_cap (optional): the coarse nodes' record counts on the host and the records rec0 has room for -- with
+// both, level 1 runs WITHOUT its histogram where the regions fit (see sk_spec_span): mid buckets are regions of len / 2^b1
+// + 12.5 % + 72 slots, the sweep reserves slots from cursors and counts the k-mers per mid bucket itself; a region that
+// overflows (repeats) sends the level through the exact path (histogram, prefix, sweep).
 static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *coarse, u32 n_coarse, void *rec0, u64 n_recs, u64 n,
-                       void **recs, Node **fin, u32 *n_fin, SkHeavy *heavy, u64 *n_kmers)
+                       void **recs, Node **fin, u32 *n_fin, SkHeavy *heavy, u64 *n_kmers, const u32 *host_lens = nullptr,
+                       u64 rec0_cap = 0)
 {
     hipStream_t st = ctx->stream;
     const int b1 = g.b1;
@@ -1515,29 +1531,78 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     u32 *kcount = nullptr;
     RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &kcount));
     HIP_TRY(hipMemsetAsync(kcount, 0, (size_t)std::max<u32>(l1.n_next, 1) * sizeof(u32), st));
-    prof_mark(ctx, "sk_hist1");
-    HIP_TRY(launch_sk_hist1(l0.next, l1.chunks, l1.n_chunks, rec0, l1.hist, kcount, st));
-    prof_mark(ctx, "sk_prefix1");
-    HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st, n_coarse));
-    HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
-    // ---- skew check on the k-mers per mid bucket, before their records move (the list is short: host)
-    std::vector<u32> kc(l1.n_next), rcn(l1.n_next);
     u32 *d_lens = nullptr;
-    RC_TRY(ps.alloc(std::max<u32>(l1.n_next, 1), &d_lens));
-    HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
-    {
-        const size_t nb = (size_t)l1.n_next * sizeof(u32);
-        if (2 * nb <= MAILBOX_BYTES - 8) {        // both lists through the pinned mailbox, one wait (its last word is read_back's flag)
+    RC_TRY(ps.alloc((size_t)l1.n_next + 4, &d_lens));      // (+ the speculative sweep's three status words)
+    u32 *gcur = nullptr;
+    RC_TRY(ps.alloc((size_t)std::max<u32>(l1.n_chunks, 1) * ROW_STRIDE, &gcur));
+    std::vector<u32> kc(l1.n_next), rcn((size_t)l1.n_next + 4);
+    // mid-bucket k-mer and record counts to the host (the list is short), with `extra` words behind the record counts
+    auto lens_to_host = [&](u32 extra) -> int {
+        const size_t nb = (size_t)l1.n_next * sizeof(u32), nb2 = nb + (size_t)extra * sizeof(u32);
+        if (nb + nb2 <= MAILBOX_BYTES - 8) {      // both lists through the pinned mailbox, one wait (its last word is read_back's flag)
             char *mb = reinterpret_cast<char *>(ctx->mailbox);
             HIP_TRY(hipMemcpyAsync(mb, kcount, nb, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(mb + nb, d_lens, nb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(mb + nb, d_lens, nb2, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             memcpy(kc.data(), mb, nb);
-            memcpy(rcn.data(), mb + nb, nb);
+            memcpy(rcn.data(), mb + nb, nb2);
         } else {
             HIP_TRY(hipMemcpyAsync(kc.data(), kcount, nb, hipMemcpyDeviceToHost, st));
-            RC_TRY(read_back(ctx, rcn.data(), d_lens, nb));
+            RC_TRY(read_back(ctx, rcn.data(), d_lens, nb2));
         }
+        return DNAGPU_OK;
+    };
+    // ---- speculative: no histogram.  The regions must fit both record buffers (level 2 writes a mid bucket's final
+    // buckets back into its range of rec0).
+    u64 span = 0;
+    bool even = true;
+    if (host_lens) {
+        // Repeats show at the coarse level already: a repeated stretch sends its records to the few buckets of its minimizers
+        // (half a sequence of one tiled 1000-base motif doubles ~110 of 136 coarse buckets; random sequence fills them to
+        // within 0.3 %).  Uneven coarse buckets (2 % over the mean of the non-empty ones) take the exact level at once,
+        // instead of paying for a speculative sweep that will overflow.
+        u64 tot = 0, big = 0, used = 0;
+        for (u32 i = 0; i < n_coarse; i++) {
+            span += sk_spec_span(host_lens[i], b1);
+            tot += host_lens[i];
+            big = std::max<u64>(big, host_lens[i]);
+            used += host_lens[i] ? 1 : 0;
+        }
+        even = used == 0 || (double)big * (double)used <= 1.02 * (double)tot + 64.0 * (double)used;
+    }
+    bool spec = host_lens && even && !(ctx->debug_flags & DNAGPU_DEBUG_NO_SPEC1) && span <= rec0_cap && span <= 0xFFFFFFFFull &&
+                n_coarse <= (u32)sk_max_c0() && l1.n_chunks > 0;
+    bool moved = false;
+    if (spec) {
+        u32 *sp = nullptr;
+        RC_TRY(ps.alloc((size_t)2 * n_coarse, &sp));
+        u32 *status = d_lens + l1.n_next;         // [0] slots of all regions, [1] past 2^32, [2] overflow
+        prof_mark(ctx, "sk_spec1");
+        HIP_TRY(launch_sk_spec_regions(l0.next, n_coarse, sp, status, gcur, st));
+        RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(std::max(n_recs, span), 1) * 16, &rec1));
+        ps.ptrs.push_back(rec1);
+        prof_mark(ctx, "sk_scatter1");
+        HIP_TRY(launch_sk_scatter1_spec(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, gcur, sp, kcount, status + 2, st));
+        HIP_TRY(launch_sk_spec_nodes(l0.next, l0.n_next, sp, gcur, l1.next, status + 2, st));
+        HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
+        RC_TRY(lens_to_host(3));
+        const u32 *stw = rcn.data() + l1.n_next;
+        if (stw[0] != (u32)span || stw[1] || stw[2] || (ctx->debug_flags & DNAGPU_DEBUG_SPEC1_OVERFLOW)) {
+            spec = false;                          // (a region overflowed, or the test flag says so: the exact level, into the same rec1)
+            HIP_TRY(hipMemsetAsync(kcount, 0, (size_t)std::max<u32>(l1.n_next, 1) * sizeof(u32), st));
+        } else {
+            moved = true;
+        }
+    }
+    if (!spec) {
+        prof_mark(ctx, "sk_hist1");
+        HIP_TRY(launch_sk_hist1(l0.next, l1.chunks, l1.n_chunks, rec0, l1.hist, kcount, st));
+        prof_mark(ctx, "sk_prefix1");
+        HIP_TRY(launch_level_prefix(l0.next, l1.chunks, l1.n_chunks, n_coarse, (u32)chunk_recs, l1.hist, l1.tot, st, n_coarse));
+        HIP_TRY(launch_level_children(l0.next, l0.n_next, l1.tot, l1.next, nullptr, nullptr, nullptr, 0, st));
+        // ---- skew check on the k-mers per mid bucket, before their records move
+        HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
+        RC_TRY(lens_to_host(0));
     }
     // heavy: too many k-mers, or too many records for the one workgroup that regroups a mid bucket (its tiles are serial)
     const bool forced = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) != 0;
@@ -1564,18 +1629,20 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
             }
         // DNAGPU_SK_SKEWED leaves this function in two cases only: with DNAGPU_DEBUG_HEAVY_EXPAND (the older path, kept for
         // the tests: heavy mid buckets are expanded as a whole, and a set that is mostly heavy is cheaper through the tree
-        // from scratch -- count_core -- or as one key node per coarse bucket -- count_sk_received), or with more heavy mid
-        // buckets than the chunked split below plans for (32768: not reachable with 2^32 rows, a guard).
+        // from scratch -- count_core -- or as one key node per coarse bucket -- count_sk_received; rec0 is still what it
+        // was: level 1 only reads it), or with more heavy mid buckets than the chunked split below plans for (32768: not
+        // reachable with 2^32 rows, a guard).
         if (((ctx->debug_flags & DNAGPU_DEBUG_HEAVY_EXPAND) && heavy->total * 2 > run) || heavy_idx.size() > 32768)
             return DNAGPU_SK_SKEWED;
     }
 
-    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
-    ps.ptrs.push_back(rec1);
-    prof_mark(ctx, "sk_scatter1");
-    {   // the mid buckets' cursors start at their exact bases (the prefix of the histogram); tiles reserve their slots there
-        u32 *gcur = nullptr;
-        RC_TRY(ps.alloc((size_t)std::max<u32>(l1.n_chunks, 1) * ROW_STRIDE, &gcur));
+    if (!moved) {
+        if (!rec1) {
+            RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(n_recs, 1) * 16, &rec1));
+            ps.ptrs.push_back(rec1);
+        }
+        prof_mark(ctx, "sk_scatter1");
+        // the mid buckets' cursors start at their exact bases (the prefix of the histogram); tiles reserve their slots there
         HIP_TRY(hipMemcpyAsync(gcur, l1.tot, (size_t)std::max<u32>(l1.n_chunks, 1) * ROW_STRIDE * sizeof(u32), hipMemcpyDeviceToDevice, st));
         HIP_TRY(launch_sk_scatter1(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, l1.hist, l1.tot, st, false, gcur));
     }
@@ -1648,8 +1715,13 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     u64 n_recs = 0, n_kmers = 0;
     std::vector<Node> kids;
     SkHeavy heavy;
-    RC_TRY(sk_level0(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs));
-    RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n, &recs, &fin, &n_fin, &heavy, &n_kmers));
+    u64 rec0_cap = 0;
+    RC_TRY(sk_level0(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs, &rec0_cap));
+    std::vector<u32> lens(kids.size());
+    for (size_t i = 0; i < kids.size(); i++)
+        lens[i] = kids[i].len;
+    RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n, &recs, &fin, &n_fin, &heavy, &n_kmers,
+                       lens.size() == n_coarse ? lens.data() : nullptr, rec0_cap));
     return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n, k, h);
 }
 
@@ -1661,8 +1733,19 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
 // rec0 (pool memory; this takes it over and returns it to the pool) = the records of the coarse buckets, bucket after
 // bucket: bucket d = blen[d] records at boff[d] (n_coarse = 2^r0bits entries).  Everything queued on ctx->stream
 // behind whatever filled rec0.
+// the records a landing buffer of the buckets blen[] should have room for, so that level 1 can run without its histogram
+static u64 sk_received_cap(const std::vector<u64> &blen, u32 n_coarse, const SkGeom &g)
+{
+    u64 n_recs = 0, span = 0;
+    for (u32 d = 0; d < n_coarse; d++) {
+        n_recs += blen[d];
+        span += sk_spec_span((u32)std::min<u64>(blen[d], 0xFFFFFFFFull), g.b1);
+    }
+    return span <= 0xFFFFFFFFull ? std::max(n_recs, span) : n_recs;
+}
+
 static int count_sk_received(dnagpu_ctx *ctx, void *rec0, const std::vector<u64> &boff, const std::vector<u64> &blen, const SkGeom &g,
-                             int k, dnagpu_hist *h)
+                             int k, dnagpu_hist *h, u64 rec0_cap = 0)
 {
     hipStream_t st = ctx->stream;
     PoolScope ps(ctx);
@@ -1685,7 +1768,10 @@ static int count_sk_received(dnagpu_ctx *ctx, void *rec0, const std::vector<u64>
     u32 n_fin = 0;
     u64 n_kmers = 0;
     SkHeavy heavy;
-    int rc = sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, 0, &recs, &fin, &n_fin, &heavy, &n_kmers);
+    std::vector<u32> lens(n_coarse);
+    for (u32 d = 0; d < n_coarse; d++)
+        lens[d] = (u32)blen[d];
+    int rc = sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, 0, &recs, &fin, &n_fin, &heavy, &n_kmers, lens.data(), rec0_cap);
     if (rc == DNAGPU_SK_SKEWED) {
         // every coarse bucket as one "heavy" bucket: keys, then the ordinary levels (sk_levels12 has not moved anything yet)
         heavy = SkHeavy();
@@ -1723,7 +1809,8 @@ static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u6
         return DNAGPU_OK;
     }
     void *rec0 = nullptr;
-    RC_TRY(pool_alloc(ctx, (size_t)n_recs * 16, &rec0));
+    const u64 cap0 = sk_received_cap(blen, n_coarse, g);    // (room for the regions of a level 1 without its histogram)
+    RC_TRY(pool_alloc(ctx, (size_t)cap0 * 16, &rec0));
     std::vector<u64> fill(boff.begin(), boff.end() - 1);
     for (u32 i = 0; i < n_pieces; i++)
         if (piece_len[i]) {
@@ -1736,7 +1823,7 @@ static int count_sk_records(dnagpu_ctx *ctx, const void *const *pieces, const u6
             }
             fill[piece_bucket[i]] += piece_len[i];
         }
-    return count_sk_received(ctx, rec0, boff, blen, g, k, h);
+    return count_sk_received(ctx, rec0, boff, blen, g, k, h, cap0);
 }
 
 static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, u32 n_fin, const SkHeavy &heavy, u64 n, int k,
@@ -3374,7 +3461,7 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
                 if (n_recs > 0xFFFFFFFFull)
                     return drop(DNAGPU_ERR_TOO_LARGE, "too many records for one owner");
                 if (n_recs) {
-                    const int arc = pool_alloc(c, (size_t)n_recs * 16, &bufs[(size_t)p]);
+                    const int arc = pool_alloc(c, (size_t)sk_received_cap(blen, n_coarse, g) * 16, &bufs[(size_t)p]);
                     if (arc != DNAGPU_OK)
                         return drop(arc, dnagpu_last_error());
                 }
@@ -3444,7 +3531,8 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
                     return drop(DNAGPU_ERR_OOM, "host allocation failed");
                 void *buf = bufs[(size_t)p];
                 bufs[(size_t)p] = nullptr;                        // (count_sk_received takes the buffer over)
-                const int crc = count_sk_received(c, buf, boffs[(size_t)p], blens[(size_t)p], g, k, part);
+                const int crc = count_sk_received(c, buf, boffs[(size_t)p], blens[(size_t)p], g, k, part,
+                                                  sk_received_cap(blens[(size_t)p], n_coarse, g));
                 if (crc != DNAGPU_OK) {
                     delete part;
                     return drop(crc, dnagpu_last_error());

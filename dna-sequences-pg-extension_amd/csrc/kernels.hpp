@@ -174,6 +174,16 @@ hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks,
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,
                               const u32 *tot, hipStream_t s, bool by_d2 = false, u32 *gcur = nullptr);
 // (by_d2: the same kernels on the 4-bit digit d2 -- the heavy mid buckets' split into final buckets)
+// Level 1 WITHOUT its histogram (speculative): every mid bucket is a region of the destination buffer, sk_spec_span(len, bits)
+// slots for a node of len records (host and device share the formula); spec = 2 words per node, out = 3 words (slots of all
+// regions; 1 if they pass 2^32; the sweep's overflow flag), gcur = rows of ROW_STRIDE cursors (row = the node's first chunk).
+// The sweep counts the k-mers per mid bucket into kcount; launch_sk_spec_nodes writes the mid nodes and raises *over too.
+u64 sk_spec_span(u32 len, int bits);
+hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s);
+hipError_t launch_sk_scatter1_spec(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, u32 *gcur,
+                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s);
+hipError_t launch_sk_spec_nodes(const Node *nodes, u32 n_nodes, const u32 *spec, const u32 *gcur, Node *next, u32 *over,
+                                hipStream_t s);
 hipError_t launch_sk_heavy_finals(const Node *kids, u32 n, const u32 *kcount, Node *out, hipStream_t s);
 // buckets sk_count does not take, expanded to keys in record order (no host step): slices of sk_flat_slice() records
 // per bucket (n_slices[i], then after an exclusive scan slice_first[i]; slice_rec0 = first record, slice_nrec = records),

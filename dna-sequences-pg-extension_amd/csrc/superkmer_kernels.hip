@@ -520,13 +520,21 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
 // one read and the staging; the chunk's last, partial tile ranks an index list and gathers.
 constexpr int SK1_ITEMS = 8;
 constexpr int SK1_TILE = SK1_NT * SK1_ITEMS;
+// SPEC (level 1 without its histogram): the mid buckets are REGIONS of the destination buffer -- spec[2 node] = start of
+// the node's first, spec[2 node + 1] = records each holds, the cursors start at the regions' starts (sk_spec_*_kernel below)
+// -- and the sweep counts the k-mers per mid bucket itself (kcount).  A record that does not fit its region is dropped and
+// raises *over: the caller then runs the exact level (histogram, prefix, this kernel without SPEC).
+template <bool SPEC>
 __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
                                                              u32 n_chunks, const ull2_t *__restrict__ src_all,
                                                              ull2_t *__restrict__ dst_all, const u32 *__restrict__ hist,
-                                                             const u32 *__restrict__ tot, int shift, u32 *__restrict__ gcur)
+                                                             const u32 *__restrict__ tot, int shift, u32 *__restrict__ gcur,
+                                                             const u32 *__restrict__ spec, u32 *__restrict__ kcount,
+                                                             u32 *__restrict__ over)
 {
     __shared__ u32 cnt[ROW_STRIDE];
     __shared__ u32 gpos[ROW_STRIDE];
+    __shared__ u32 kcs[SPEC ? ROW_STRIDE : 1];   // SPEC: k-mers of the chunk's records per digit
     // a full tile: half of its records at a time, in sorted order (64 KB); a partial tile: the index list (16 KB of it)
     __shared__ __attribute__((aligned(16))) ull2_t stage[SK1_TILE / 2];
     unsigned short *idx = reinterpret_cast<unsigned short *>(stage);
@@ -550,6 +558,14 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     u32 *gc = gcur ? gcur + (u64)nd.chunk_base * ROW_STRIDE : nullptr;
     const ull2_t *src = src_all + (u64)nd.start + ch.off;
     const u32 dmask = R - 1;
+    u32 reg0 = 0, rcap = ~0u;                      // SPEC: digit d's region is [reg0 + d rcap, reg0 + (d + 1) rcap)
+    bool dropped = false;
+    if (SPEC) {
+        reg0 = spec[2 * ch.node];
+        rcap = spec[2 * ch.node + 1];
+        for (u32 d = tid; d < R; d += SK1_NT)
+            kcs[d] = 0;
+    }
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
         asm volatile("" : "+v"(tid));              // (thread-derived addresses recomputed per tile, not held: the kernel lives on 64 registers)
@@ -568,8 +584,12 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 rec[j] = src[t0 + tid + j * SK1_NT];
             u32 pos[SK1_ITEMS];
 #pragma unroll
-            for (int j = 0; j < SK1_ITEMS; j++)
-                pos[j] = atomicAdd(&cnt[(u32)(rec[j].y >> shift) & dmask], 1u);
+            for (int j = 0; j < SK1_ITEMS; j++) {
+                const u32 dg = (u32)(rec[j].y >> shift) & dmask;
+                pos[j] = atomicAdd(&cnt[dg], 1u);
+                if (SPEC)
+                    atomicAdd(&kcs[dg], (u32)((rec[j].y >> 44) & 31) + 1u);
+            }
             __syncthreads();
             block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
             u32 got = 0;
@@ -578,6 +598,8 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 const u32 c = ((u32)tid + 1 < R ? cnt[tid + 1] : n_tile) - cnt[tid];
                 if (c)
                     got = atomicAdd(&gc[tid], c);
+                if (SPEC && c && (u64)got + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
+                    dropped = true;
             }
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++)
@@ -598,7 +620,9 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const u32 d = (u32)(r.y >> shift) & dmask;
                     // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
                     // this workgroup's next tile -- completes them; kept in L2 they merge more often: 3.44 -> 3.30 ms)
-                    dst_all[gpos[d] + (sl - cnt[d])] = r;
+                    const u32 p = gpos[d] + (sl - cnt[d]);
+                    if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
+                        dst_all[p] = r;
                 }
                 __syncthreads();
             }
@@ -613,14 +637,20 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
                     dig[j] = (u32)(m >> shift) & dmask;
                     rank[j] = atomicAdd(&cnt[dig[j]], 1u);
+                    if (SPEC)
+                        atomicAdd(&kcs[dig[j]], (u32)((m >> 44) & 31) + 1u);
                 }
             }
             __syncthreads();
             block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
             if (gc && (u32)tid < R) {
                 const u32 c = ((u32)tid + 1 < R ? cnt[tid + 1] : n_tile) - cnt[tid];
-                if (c)
-                    gpos[tid] = atomicAdd(&gc[tid], c);
+                if (c) {
+                    const u32 got = atomicAdd(&gc[tid], c);
+                    gpos[tid] = got;
+                    if (SPEC && (u64)got + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
+                        dropped = true;
+                }
             }
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
@@ -635,7 +665,9 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 if (sl < n_tile) {
                     const ull2_t r = src[t0 + idx[sl]];
                     const u32 d = (u32)(r.y >> shift) & dmask;
-                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (sl - cnt[d])]);
+                    const u32 p = gpos[d] + (sl - cnt[d]);
+                    if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
+                        __builtin_nontemporal_store(r, &dst_all[p]);
                 }
             }
             __syncthreads();
@@ -649,6 +681,106 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             __syncthreads();
         }
     }
+    if (SPEC) {
+        __syncthreads();
+        for (u32 d = tid; d < R; d += SK1_NT)
+            if (kcs[d])
+                atomicAdd(&kcount[nd.child_base + d], kcs[d]);
+        if (dropped)
+            *over = 1u;
+    }
+}
+
+// The regions of a speculative level 1: a node of len records split R ways gives each child len / R + 12.5 % + 72 slots,
+// whole 128-byte lines (on random sequence a mid bucket is Poisson around ~4,800: the slack is > 8 sigma).  Host and
+// device use this one formula (the host sizes the buffers with it).
+__host__ __device__ inline u32 sk_spec_cap(u32 len, u32 R)
+{
+    return ((u32)(((u64)len + (len >> 3)) / R) + 72u + 7u) & ~7u;
+}
+u64 sk_spec_span(u32 len, int bits) { return len ? (u64)sk_spec_cap(len, 1u << bits) << bits : 0; }
+
+// spec[2 i] = first slot of node i's regions, spec[2 i + 1] = slots per child; out[0] = slots of all, out[1] = 1 if they
+// pass 2^32.  One workgroup (at most 256 nodes: the coarse buckets).
+__global__ __launch_bounds__(SK_MAX_C0) void sk_spec_caps_kernel(const Node *__restrict__ nodes, u32 n_nodes, u32 *__restrict__ spec,
+                                                                u32 *__restrict__ out)
+{
+    __shared__ u64 span[SK_MAX_C0];
+    const u32 i = threadIdx.x;
+    u32 cap = 0;
+    u64 sp = 0;
+    if (i < n_nodes && nodes[i].split) {
+        cap = sk_spec_cap(nodes[i].len, 1u << nodes[i].split);
+        sp = (u64)cap << nodes[i].split;
+    }
+    span[i] = sp;
+    __syncthreads();
+    if (i == 0) {
+        u64 run = 0;
+        for (u32 q = 0; q < (u32)SK_MAX_C0; q++) {
+            const u64 c = span[q];
+            span[q] = run;
+            run += c;
+        }
+        out[0] = (u32)(run < 0xFFFFFFFFull ? run : 0xFFFFFFFFull);
+        out[1] = run > 0xFFFFFFFFull ? 1u : 0u;
+        out[2] = 0;                                // (the sweep's overflow flag)
+    }
+    __syncthreads();
+    if (i < n_nodes) {
+        spec[2 * i] = (u32)(span[i] < 0xFFFFFFFFull ? span[i] : 0xFFFFFFFFull);
+        spec[2 * i + 1] = cap;
+    }
+}
+
+// the cursors at the regions' starts (a workgroup per node, a thread per child)
+__global__ __launch_bounds__(ROW_STRIDE) void sk_spec_init_kernel(const Node *__restrict__ nodes, u32 n_nodes, const u32 *__restrict__ spec,
+                                                                 u32 *__restrict__ gcur)
+{
+    const u32 i = blockIdx.x, d = threadIdx.x;
+    if (i >= n_nodes)
+        return;
+    const Node nd = nodes[i];
+    if (nd.split && d < (1u << nd.split))
+        gcur[(u64)nd.chunk_base * ROW_STRIDE + d] = spec[2 * i] + d * spec[2 * i + 1];
+}
+
+// the mid nodes a speculative sweep leaves (what level_children makes of a histogram): start = region start, len = records
+// drawn; a cursor past its region's end raises *over
+__global__ __launch_bounds__(ROW_STRIDE) void sk_spec_nodes_kernel(const Node *__restrict__ nodes, u32 n_nodes, const u32 *__restrict__ spec,
+                                                                  const u32 *__restrict__ gcur, Node *__restrict__ next,
+                                                                  u32 *__restrict__ over)
+{
+    const u32 i = blockIdx.x, d = threadIdx.x;
+    if (i >= n_nodes)
+        return;
+    const Node nd = nodes[i];
+    if (nd.split == 0) {
+        if (d == 0) {
+            Node o = nd;
+            o.split = 0;
+            next[nd.child_base] = o;
+        }
+        return;
+    }
+    if (d >= (1u << nd.split))
+        return;
+    const int bits = (int)nd.split, rem = (int)(nd.meta & 0xff);
+    const u32 cap = spec[2 * i + 1], start = spec[2 * i] + d * cap;
+    u32 used = gcur[(u64)nd.chunk_base * ROW_STRIDE + d] - start;
+    if (used > cap) {
+        used = cap;
+        *over = 1u;
+    }
+    Node c;
+    c.start = start;
+    c.len = used;
+    c.meta = (u32)(rem - bits) | ((nd.meta & NODE_BUF) ^ NODE_BUF) | ((bits == rem) ? NODE_TERMINAL : 0u);
+    c.split = 0;
+    c.prefix = nd.prefix | ((u64)d << (rem - bits));
+    c.child_base = 0;
+    c.chunk_base = 0;
+    next[nd.child_base + d] = c;
 }
 
 // exclusive scan over lanes 0..15 (one DPP row); lanes >= 16 get garbage
@@ -1992,8 +2124,40 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
 {
     if (n_chunks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_scatter1_kernel, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
-                       reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), hist, tot, by_d2 ? 59 : 49, gcur);
+    hipLaunchKernelGGL(sk_scatter1_kernel<false>, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
+                       reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), hist, tot, by_d2 ? 59 : 49, gcur,
+                       nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// level 1 without its histogram: regions (spec: 2 words per node; out: 3 words -- slots of all regions, 1 if past 2^32, the
+// sweep's overflow flag), cursors, the sweep (k-mers per mid bucket into kcount), the mid nodes
+hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s)
+{
+    if (n_nodes == 0 || n_nodes > (u32)SK_MAX_C0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sk_spec_caps_kernel, dim3(1), dim3(SK_MAX_C0), 0, s, nodes, n_nodes, spec, out);
+    hipLaunchKernelGGL(sk_spec_init_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_scatter1_spec(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, u32 *gcur,
+                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s)
+{
+    if (n_chunks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_scatter1_kernel<true>, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
+                       reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), nullptr, nullptr, 49, gcur, spec,
+                       kcount, over);
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_spec_nodes(const Node *nodes, u32 n_nodes, const u32 *spec, const u32 *gcur, Node *next, u32 *over,
+                                hipStream_t s)
+{
+    if (n_nodes == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_spec_nodes_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur, next, over);
     return hipGetLastError();
 }
 

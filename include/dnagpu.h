@@ -389,6 +389,12 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * buffers already returned) and fails with DNAGPU_ERR_INTERNAL -- dnagpu_last_error() names the buffer's size -- if a
  * kernel wrote past the end of one.  Complements DNAGPU_DEBUG_POISON_POOL (reads of memory a call never wrote). */
 #define DNAGPU_DEBUG_GUARD_POOL 8u
+/* Level 1 of the super-k-mer engine normally runs WITHOUT its histogram: every mid bucket is a region of the record buffer
+ * sized from its parent (mean + 12.5 % + 72 records), the sweep reserves slots from cursors, and a region that overflows
+ * (repeats) sends the level through the exact path (histogram, prefix, sweep).  DNAGPU_DEBUG_NO_SPEC1 always takes the exact
+ * path; DNAGPU_DEBUG_SPEC1_OVERFLOW runs the speculative sweep and then treats it as overflowed (tests of the fall-back). */
+#define DNAGPU_DEBUG_NO_SPEC1 16u
+#define DNAGPU_DEBUG_SPEC1_OVERFLOW 32u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

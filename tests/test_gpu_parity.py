@@ -662,6 +662,43 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     d.free()
 
 
+@pytest.mark.parametrize("n,k,kind", [(3_000_000, 31, "random"), (3_000_001, 25, "planted"), (20_000_000, 27, "random"),
+                                      (6_000_000, 21, "planted")])
+def test_level1_speculative_and_exact_agree(ctx, pkg, n, k, kind):
+    """level 1 of the record engine without its histogram (the default: mid buckets are regions sized from their parent),
+    the exact level (DNAGPU_DEBUG_NO_SPEC1) and the fall-back after an overflow -- forced (DNAGPU_DEBUG_SPEC1_OVERFLOW) and
+    real: copies of one 64-base segment planted all over a random sequence (coarse buckets stay even, so the speculative
+    sweep runs, and the segment's mid buckets overflow their regions) -- all give the oracle's groups"""
+    words = orc.synth_words(0xC0FFEE + n, n)
+    if kind == "planted":
+        rng = np.random.default_rng(n)
+        seg = words[1000:1002].copy()
+        for p in rng.integers(0, len(words) - 3, size=4000):
+            words[p:p + 2] = seg
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False))
+    ctx.set_profiling(True)
+    for name, flag in (("speculative", 0), ("exact", pkg.DEBUG_NO_SPEC1), ("overflow forced", pkg.DEBUG_SPEC1_OVERFLOW)):
+        ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | flag)
+        try:
+            h = ctx.count_kmers_unordered(d, k)
+        finally:
+            ctx.set_debug(0)
+        phases = {a for a, _ in ctx.last_phase_times()}
+        assert not h.is_sorted
+        check_hist_unordered(h, ok, oc, f"level 1 {name}: n={n} k={k} {kind}")
+        h.free()
+        # which way level 1 went: the speculative sweep ("sk_spec1") alone on random sequence, followed by the exact level
+        # ("sk_hist1") where the planted copies -- or the test flag -- overflowed a region; the exact level alone when asked
+        if name == "exact":
+            assert "sk_spec1" not in phases and "sk_hist1" in phases, phases
+        else:
+            assert "sk_spec1" in phases, phases
+            assert ("sk_hist1" in phases) == (kind == "planted" or name == "overflow forced"), (name, kind, phases)
+    ctx.set_profiling(False)
+    d.free()
+
+
 @pytest.mark.parametrize("kind", ["motif1000", "motif37", "motif100000", "polyA", "half-polyA", "quarter-polyA", "AT",
                                   "small-polyA", "small-AT"])
 @pytest.mark.parametrize("k", [31, 21])
