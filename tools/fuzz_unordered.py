@@ -1,6 +1,6 @@
 """Randomised parity soak of the unordered count (super-k-mer engine, all its paths) against the oracle: random lengths,
 k in 21..32, repeat motifs, planted heavy stretches, windows, and the debug flags that steer the paths (engine forced;
-heavy mid buckets expanded instead of split).  Usage: python tools/fuzz_unordered.py [cases] [max_n] [seed]"""
+heavy mid buckets expanded instead of split; level 1 speculative / exact / forced fall-back).  Usage: python tools/fuzz_unordered.py [cases] [max_n] [seed]"""
 import os
 import sys
 import time
@@ -55,6 +55,8 @@ with pkg.Context(0) as ctx:
         keys = orc.generate_kmers(words, n, k, first, count, faithful=False)
         ok, oc = orc.count_keys(keys)
         flags = int(rng.choice([pkg.DEBUG_FORCE_SUPERKMER, pkg.DEBUG_FORCE_SUPERKMER, pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_HEAVY_EXPAND]))
+        # level 1: speculative regions (the default; repeats overflow them and fall back), the exact level, the forced fall-back
+        flags |= int(rng.choice([0, 0, pkg.DEBUG_NO_SPEC1, pkg.DEBUG_SPEC1_OVERFLOW]))
         ctx.set_debug(flags)
         try:
             h = ctx.count_kmers_unordered(d, k, first, count)
