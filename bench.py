@@ -212,7 +212,10 @@ def main():
                 # the chunks (RCCL) and counts the keys this rank owns over the whole sequence
                 h, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
             distinct[0] = h.distinct
+            per_step = {}                          # (a phase name appears once per bucket group of the exchange: their sum)
             for name, ms in (engine.phase_times() if use_records else ctx.last_phase_times()):
+                per_step[name] = per_step.get(name, 0.0) + ms
+            for name, ms in per_step.items():
                 phases_acc.setdefault(name, []).append(ms)
             h.free()
 
@@ -410,7 +413,10 @@ def main_one_process(args):
     def step():
         hs = count_fn(mdna, k)
         distinct[0] = sum(h.distinct for h in hs)
-        for name, ms in multi.ranks[0].last_phase_times():
+        per_step = {}                              # (the pipelined exchange counts an owner's buckets group by group: a phase
+        for name, ms in multi.ranks[0].last_phase_times():   # name then appears once per group -- their SUM is the step's)
+            per_step[name] = per_step.get(name, 0.0) + ms
+        for name, ms in per_step.items():
             phases_acc.setdefault(name, []).append(ms)
         if use_records:
             for name, v in multi.last_times().items():

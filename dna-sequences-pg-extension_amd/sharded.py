@@ -147,19 +147,23 @@ class GpuEngine:
         r = self.ctx.sk_records(dna, k, 0, count, global_rows)
         self._records = r
         self._phases0 = list(self.ctx.last_phase_times())      # (level 0; the count's phases follow in count_records)
+        self._phases1 = []
         if r.n_records == 0:
             return self.empty(0), [0] * (r.n_buckets + 1)
         return torch.as_tensor(_DevArray(r.device_ptr, 2 * r.n_records), device=self.device), [int(x) for x in r.offsets]
 
     def phase_times(self):
         """phase times of the last sharded count: the record cut (if any) followed by the count"""
-        return list(getattr(self, "_phases0", [])) + list(self.ctx.last_phase_times())
+        return list(getattr(self, "_phases0", [])) + list(getattr(self, "_phases1", []))
 
     def count_records(self, recv_t, pieces, k, global_rows, last=True):
         """pieces: [(offset in records inside recv_t, n_records, bucket)]"""
         torch.cuda.synchronize(self.device)
         base = recv_t.data_ptr() if recv_t.numel() else 0
-        return self.ctx.count_records([(base + 16 * off, n, b) for off, n, b in pieces if n], k, global_rows)
+        h = self.ctx.count_records([(base + 16 * off, n, b) for off, n, b in pieces if n], k, global_rows)
+        # (the pipelined exchange counts the buckets group by group: every group's phases, the same names again)
+        self._phases1 = list(getattr(self, "_phases1", [])) + list(self.ctx.last_phase_times())
+        return h
 
     def release_records(self):
         """the rank's own records (the send buffer of the exchange) go back to the pool"""
