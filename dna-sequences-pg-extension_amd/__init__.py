@@ -14,7 +14,10 @@ from .binding import (  # noqa: F401
     DEBUG_FORCE_SUPERKMER,
     DEBUG_GUARD_POOL,
     DEBUG_HEAVY_EXPAND,
+    DEBUG_NO_SLAB0,
     DEBUG_NO_SPEC1,
+    DEBUG_SLAB0,
+    DEBUG_SLAB0_OVERFLOW,
     DEBUG_SPEC1_OVERFLOW,
     Context,
     Dna,

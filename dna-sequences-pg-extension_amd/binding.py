@@ -26,6 +26,9 @@ DEBUG_HEAVY_EXPAND = 4
 DEBUG_GUARD_POOL = 8
 DEBUG_NO_SPEC1 = 16
 DEBUG_SPEC1_OVERFLOW = 32
+DEBUG_SLAB0 = 64
+DEBUG_NO_SLAB0 = 128
+DEBUG_SLAB0_OVERFLOW = 256
 
 
 def _env_debug():

@@ -1506,6 +1506,98 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
 
 // Levels 1 and 2 over coarse nodes (records of rec0, which this takes over).  n = the k-mers the records must hold
 // (0 = not known: records received from other ranks).  On success *n_kmers = the k-mers found.
+// Level 0 WITHOUT its histogram sweep (the window minima are computed once): a histogram over 1/64 of the rows (chunks of
+// four tiles, evenly spaced) gives every coarse bucket's share of a chunk's records; every chunk then reserves that share
+// + 1/32 + six standard deviations + 24 slots in the bucket's region (one returning add per digit and chunk) and fills
+// them as the exact sweep fills its histogram ranges; what it does not use becomes NULL records, which level 1 skips
+// (~10 % of the slots at 3 Gbase).  *ok = false (nothing usable produced: the caller runs the exact pair) when the sampled
+// buckets are uneven (repeats), when the regions pass 2^32 slots, or when a chunk ran out of slots.  On success the coarse
+// nodes cover their whole regions (lens[d] slots, NULL records included) and *n_recs / *rec0_cap are slots.
+constexpr u64 SK_SLAB_MIN_ROWS = (u64)1 << 29;     // (measured: 249 Mbase 2.16 vs 2.12 ms, 1 Gbase 8.31 vs 8.42, 3 Gbase 21.8 vs 22.4)
+static int sk_level0_slab(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 first, u64 n, int k, const SkGeom &g,
+                          void **rec0_out, Node **coarse, u32 *n_coarse, std::vector<u32> *lens, u64 *n_recs, u64 *rec0_cap, bool *ok)
+{
+    hipStream_t st = ctx->stream;
+    *ok = false;
+    const u32 r0n = 1u << g.r0bits;
+    Node root;
+    memset(&root, 0, sizeof root);
+    root.len = (u32)n;
+    root.meta = 32;
+    Node *cur = nullptr;
+    RC_TRY(ps.alloc(1, &cur));
+    HIP_TRY(poke(cur, &root, sizeof root, st));
+    const u64 tile = (u64)sk_tile_rows();
+    // (1024 chunks = one resident set of workgroups: a chunk's share of a bucket is then ~2,400 records, and the six
+    // standard deviations of slack it needs are 12 % of them -- with the exact pair's 4096 chunks they would be 25 %)
+    u64 chunk_rows = std::max<u64>(4 * tile, (n + 1023) / 1024);
+    chunk_rows = (chunk_rows + tile - 1) / tile * tile;
+    prof_mark(ctx, "sk_plan0");
+    SkLevel l0;
+    RC_TRY(sk_level_begin(ctx, ps, cur, 1, g.r0bits, (u32)chunk_rows, &l0));
+    if (l0.n_chunks == 0)
+        return DNAGPU_OK;
+    // ---- the sample
+    const u64 samp_len = 4 * tile, samp_stride = 64 * samp_len;
+    const u32 n_samp = (u32)((n + samp_stride - 1) / samp_stride);
+    u64 sampled = 0;
+    for (u32 i = 0; i < n_samp; i++)
+        sampled += std::min<u64>(samp_len, n - (u64)i * samp_stride);
+    Chunk *samp = nullptr;
+    u32 *est = nullptr, *slab = nullptr;
+    Node *nodes = nullptr;
+    RC_TRY(ps.alloc((size_t)n_samp, &samp));
+    RC_TRY(ps.alloc((size_t)sk_max_c0(), &est));
+    RC_TRY(ps.alloc((size_t)sk_slab_words(), &slab));
+    RC_TRY(ps.alloc((size_t)r0n, &nodes));
+    prof_mark(ctx, "sk_sample0");
+    HIP_TRY(hipMemsetAsync(est, 0, (size_t)sk_max_c0() * sizeof(u32), st));
+    HIP_TRY(launch_sk_sample_chunks(samp, n_samp, (u32)samp_stride, (u32)samp_len, (u32)n, st));
+    HIP_TRY(launch_sk_level0(false, samp, n_samp, dna->words, dna->n_words, first, k, g.c0n, (u32)g.b1, (u32)g.r0bits, nullptr, nullptr,
+                             nullptr, st, est));
+    HIP_TRY(launch_sk_slab_init(est, (u32)g.r0bits, (u32)chunk_rows, (u32)sampled, l0.n_chunks, slab, nodes, st));
+    std::vector<u32> h_est(r0n);
+    RC_TRY(read_back(ctx, h_est.data(), est, (size_t)r0n * sizeof(u32)));
+    // even buckets?  (a repeated stretch sends its records to the few buckets of its minimizers: see sk_levels12)
+    u64 tot = 0, big = 0, used = 0, span = 0, span1 = 0;
+    lens->assign(r0n, 0);
+    for (u32 d = 0; d < r0n; d++) {
+        tot += h_est[d];
+        big = std::max<u64>(big, h_est[d]);
+        used += h_est[d] ? 1 : 0;
+        const u64 len = (u64)sk_slab_cap(h_est[d], chunk_rows, sampled) * l0.n_chunks;
+        span += len;
+        if (len > 0xFFFFFFFFull)
+            return DNAGPU_OK;
+        (*lens)[d] = (u32)len;
+        span1 += sk_spec_span((u32)len, g.b1);
+    }
+    if (used == 0 || (double)big * (double)used > 1.05 * (double)tot + 64.0 * (double)used || span > 0xFFFFFFFFull)
+        return DNAGPU_OK;
+    const u64 cap = std::max<u64>(span, span1 <= 0xFFFFFFFFull ? span1 : 0);
+    void *rec0 = nullptr;
+    RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(cap, 1) * 16, &rec0));
+    prof_mark(ctx, "sk_scatter0");
+    const hipError_t e = launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, g.c0n, (u32)g.b1,
+                                          (u32)g.r0bits, nullptr, nullptr, rec0, st, slab);
+    u32 status[2] = {1, 0};
+    int rc = e == hipSuccess ? read_back(ctx, status, slab + 18 * (size_t)sk_max_c0(), sizeof status) : DNAGPU_ERR_HIP;
+    if (rc != DNAGPU_OK || status[0] || status[1] != (u32)span || (ctx->debug_flags & DNAGPU_DEBUG_SLAB0_OVERFLOW)) {
+        pool_free(ctx, rec0);                      // (ordered behind the sweep on this stream)
+        if (e != hipSuccess)
+            set_err("sk_scatter0 (slabs): %s", hipGetErrorString(e));
+        return rc;
+    }
+    ps.ptrs.push_back(rec0);
+    *rec0_out = rec0;
+    *coarse = nodes;
+    *n_coarse = r0n;
+    *n_recs = span;
+    *rec0_cap = cap;
+    *ok = true;
+    return DNAGPU_OK;
+}
+
 // host_lens / rec0_cap (optional): the coarse nodes' record counts on the host and the records rec0 has room for -- with
 // both, level 1 runs WITHOUT its histogram where the regions fit (see sk_spec_span): mid buckets are regions of len / 2^b1
 // + 12.5 % + 72 slots, the sweep reserves slots from cursors and counts the k-mers per mid bucket itself; a region that
@@ -1716,10 +1808,17 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
     std::vector<Node> kids;
     SkHeavy heavy;
     u64 rec0_cap = 0;
-    RC_TRY(sk_level0(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs, &rec0_cap));
-    std::vector<u32> lens(kids.size());
-    for (size_t i = 0; i < kids.size(); i++)
-        lens[i] = kids[i].len;
+    std::vector<u32> lens;
+    bool slabs = false;
+    const unsigned dbg = ctx->debug_flags;
+    if (!(dbg & DNAGPU_DEBUG_NO_SLAB0) && (n >= SK_SLAB_MIN_ROWS || (dbg & (DNAGPU_DEBUG_SLAB0 | DNAGPU_DEBUG_SLAB0_OVERFLOW))))
+        RC_TRY(sk_level0_slab(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &lens, &n_recs, &rec0_cap, &slabs));
+    if (!slabs) {
+        RC_TRY(sk_level0(ctx, ps, dna, first, n, k, g, &rec0, &coarse, &n_coarse, &kids, &n_recs, &rec0_cap));
+        lens.resize(kids.size());
+        for (size_t i = 0; i < kids.size(); i++)
+            lens[i] = kids[i].len;
+    }
     RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n, &recs, &fin, &n_fin, &heavy, &n_kmers,
                        lens.size() == n_coarse ? lens.data() : nullptr, rec0_cap));
     return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n, k, h);

@@ -167,8 +167,19 @@ int sk_min_k();
 int sk_minimizer_len(int k);          // m: 15 for k >= 23, 13 for k = 21, 22
 int sk_tile_rows();
 int sk_max_c0();          // most coarse buckets the level-0 sweeps support
+// aux: the histogram sweep adds its chunks' counts into ONE row aux[0 .. 2^r0bits) instead of hist rows (a sampled
+// histogram); the scatter sweep takes aux as its slab table (sk_slab_words() words, launch_sk_slab_init): level 0 WITHOUT
+// the histogram sweep -- every chunk reserves sk_slab_cap(est ...) slots of every digit's region, unused slots become NULL
+// records (bit 63 of the second word; level 1 skips them), aux[17 * sk_max_c0() + d] = records stored per digit,
+// aux[18 * sk_max_c0()] = 1 if a chunk ran out of slots, aux[18 * sk_max_c0() + 1] = slots of all regions.
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
-                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s);
+                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s,
+                            u32 *aux = nullptr);
+hipError_t launch_sk_sample_chunks(Chunk *chunks, u32 n_chunks, u32 stride, u32 len, u32 n, hipStream_t s);
+int sk_slab_words();
+u32 sk_slab_cap(u32 est, u64 chunk_rows, u64 sampled);
+hipError_t launch_sk_slab_init(const u32 *est, u32 r0bits, u32 chunk_rows, u32 sampled, u32 n_chunks, u32 *slab, Node *nodes,
+                               hipStream_t s);
 hipError_t launch_sk_hist1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *recs, u32 *hist, u32 *kcount,
                            hipStream_t s, bool by_d2 = false);
 hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, const u32 *hist,

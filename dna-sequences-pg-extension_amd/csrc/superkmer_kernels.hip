@@ -293,7 +293,7 @@ template <int W>
 __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                          const u64 *__restrict__ words, u64 n_words, u64 first,
                                                          u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n /* digits of the root's split */,
-                                                         u32 *__restrict__ hist)
+                                                         u32 *__restrict__ hist, u32 *__restrict__ accum /* or null */)
 {
     __shared__ u32 h[SK_MAX_C0 + 64];             // (+ a word per lane for the adds that count nothing)
     if (blockIdx.x >= n_chunks)
@@ -326,6 +326,12 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
         }
     }
     __syncthreads();
+    if (accum) {                                   // (the sampled histogram behind a slab sweep: one row for all chunks)
+        for (u32 d = threadIdx.x; d < r0n; d += SK_NT)
+            if (h[d])
+                atomicAdd(&accum[d], h[d]);
+        return;
+    }
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;
     for (u32 d = threadIdx.x; d < r0n; d += SK_NT)
         row[d] = h[d];
@@ -341,9 +347,16 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                                                             const u64 *__restrict__ words, u64 n_words, u64 first, int k,
                                                             u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n,
                                                             const u32 *__restrict__ hist, const u32 *__restrict__ tot,
-                                                            ull2_t *__restrict__ recs, int dbg)
+                                                            ull2_t *__restrict__ recs, int dbg,
+                                                            u32 *__restrict__ slab /* or null: see below */)
 {
+    // slab != null: level 0 WITHOUT its histogram sweep.  slab[0 .. r0n) = slots a chunk reserves of every digit's region
+    // (the host's estimate from a sampled histogram + slack), slab[SK_MAX_C0 + 16 d] = the digit's global cursor (starts
+    // at its region's start), slab[17 SK_MAX_C0 + d] += records the chunk stored, slab[18 SK_MAX_C0] = 1 if a chunk ran out
+    // of slots (the caller then runs the exact pair).  The slots a chunk does not use are filled with NULL records (bit 63
+    // of the second word), which level 1 skips.
     __shared__ u32 gpos[SK_MAX_C0];               // where the chunk's next record of each digit goes (all waves: LDS adds)
+    __shared__ u32 gend[SK_MAX_C0], gbeg[SK_MAX_C0];
     __shared__ u64 wsh_all[SK_NT / 64][66];       // per wave: the tile's packed words -- record payloads are cut from here
     __shared__ u64 list_all[SK_NT / 64][SKW_LIST + 64];   // per wave: the tile's records (see below); + an entry per lane for writes that list nothing
     __shared__ u32 ns_all[SK_NT / 64][64];         // per wave and lane: start row of the run that is open at the lane's first row
@@ -351,14 +364,27 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const Chunk ch = chunks[blockIdx.x];
-    const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
-    const u32 *trow = tot;                         // the root is node 0: its totals row is row 0
-    for (u32 d = tid; d < r0n; d += SK_NT)
-        gpos[d] = trow[d] + hrow[d];
+    if (slab) {
+        for (u32 d = tid; d < r0n; d += SK_NT) {
+            const u32 cap = slab[d];
+            const u32 base = cap ? atomicAdd(&slab[SK_MAX_C0 + 16 * d], cap) : 0u;
+            gpos[d] = base;
+            gbeg[d] = base;
+            gend[d] = base + cap;
+        }
+    } else {
+        const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
+        const u32 *trow = tot;                     // the root is node 0: its totals row is row 0
+        for (u32 d = tid; d < r0n; d += SK_NT) {
+            gpos[d] = trow[d] + hrow[d];
+            gend[d] = ~0u;
+        }
+    }
     __syncthreads();
     u64 *wsh = wsh_all[wave], *wl = list_all[wave];
     u32 *ns_tab = ns_all[wave];
     const u64 below = ((u64)1 << lane) - 1;
+    bool dropped = false;
     for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         const u64 tile_pos = first + ch.off + t0;
@@ -402,7 +428,9 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     ull2_t r;
                     r.x = lo;
                     r.y = hi;
-                    if (!SK_DBG(1))
+                    if (gslot >= gend[dg.d0])
+                        dropped = true;            // (slab mode: the chunk's slots of this digit are used up)
+                    else if (!SK_DBG(1))
                         recs[gslot] = r;
                     else if (r.x == 0x1234567 && r.y == 0x89)
                         recs[0] = r;
@@ -465,6 +493,103 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             sk_wave_fence();                       // wsh / list are rewritten by the next pass / tile
         }
     }
+    if (slab) {
+        if (dropped)
+            slab[18 * SK_MAX_C0] = 1u;
+        __syncthreads();
+        ull2_t null_rec;
+        null_rec.x = 0;
+        null_rec.y = (unsigned long long)1 << 63;
+        for (u32 d = (u32)wave; d < r0n; d += SK_NT / 64) {        // (a wave per digit: four short store chains instead of one long)
+            const u32 e = gend[d], u = gpos[d] < e ? gpos[d] : e;
+            for (u32 i = u + (u32)lane; i < e; i += 64)
+                __builtin_nontemporal_store(null_rec, &recs[i]);
+            if (lane == 0 && u > gbeg[d])
+                atomicAdd(&slab[17 * SK_MAX_C0 + d], u - gbeg[d]);
+        }
+    }
+}
+
+// the sampled chunks of a slab sweep's estimate: chunk i = rows [i * stride, i * stride + len) of the root
+__global__ __launch_bounds__(256) void sk_sample_chunks_kernel(Chunk *__restrict__ chunks, u32 n_chunks, u32 stride, u32 len, u32 n)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunks)
+        return;
+    const u64 off = (u64)i * stride;
+    Chunk c;
+    c.node = 0;
+    c.off = (u32)off;
+    c.len = off >= (u64)n ? 0u : (u32)((u64)len < (u64)n - off ? (u64)len : (u64)n - off);
+    c.pad = 0;
+    chunks[i] = c;
+}
+
+// Slots a chunk reserves of a digit's region: the digit's share of a chunk's records by the sampled histogram (est records
+// among `sampled` rows; chunks of chunk_rows rows), + 1/32 + six standard deviations + 24, whole 128-byte lines.  Host and
+// device share the formula (the host sizes the buffers with it).
+__host__ __device__ inline u32 sk_isqrt(u64 v)
+{
+    u64 r = 0, bit = (u64)1 << 62;
+    while (bit > v)
+        bit >>= 2;
+    while (bit) {
+        if (v >= r + bit) {
+            v -= r + bit;
+            r = (r >> 1) + bit;
+        } else {
+            r >>= 1;
+        }
+        bit >>= 2;
+    }
+    return (u32)r;
+}
+__host__ __device__ inline u32 sk_slab_cap_of(u32 est, u64 chunk_rows, u64 sampled)
+{
+    if (est == 0)
+        return 0;                                  // (a digit the sample never saw: a record of it overflows at once -> exact pair)
+    const u64 e = ((u64)est * chunk_rows) / sampled + 1;   // (a FULL chunk's share: the last chunk of a sequence may be shorter)
+    return (u32)((e + e / 32 + 6 * (u64)sk_isqrt(e) + 24 + 7) & ~(u64)7);
+}
+u32 sk_slab_cap(u32 est, u64 chunk_rows, u64 sampled) { return sk_slab_cap_of(est, chunk_rows, sampled); }
+
+// slab[] from the sampled histogram est[] (see sk_scatter0_kernel): per-chunk slots, cursors at the regions' starts, the
+// counters zeroed; nodes[d] = the coarse node of digit d (its region: n_chunks slabs, NULL records included)
+__global__ __launch_bounds__(SK_MAX_C0) void sk_slab_init_kernel(const u32 *__restrict__ est, u32 r0n, u32 chunk_rows, u32 sampled,
+                                                                u32 n_chunks, u32 child_meta, u32 *__restrict__ slab,
+                                                                Node *__restrict__ nodes)
+{
+    __shared__ u64 sc[SK_MAX_C0];
+    const u32 d = threadIdx.x;
+    const u32 cap = d < r0n ? sk_slab_cap_of(est[d], chunk_rows, sampled) : 0u;
+    sc[d] = (u64)cap * n_chunks;
+    __syncthreads();
+    if (d == 0) {
+        u64 run = 0;
+        for (u32 i = 0; i < (u32)SK_MAX_C0; i++) {
+            const u64 c = sc[i];
+            sc[i] = run;
+            run += c;
+        }
+        slab[18 * SK_MAX_C0] = 0;
+        slab[18 * SK_MAX_C0 + 1] = (u32)(run < 0xFFFFFFFFull ? run : 0xFFFFFFFFull);
+    }
+    __syncthreads();
+    if (d < r0n) {
+        const u32 start = (u32)(sc[d] < 0xFFFFFFFFull ? sc[d] : 0xFFFFFFFFull);
+        slab[d] = cap;
+        slab[SK_MAX_C0 + 16 * d] = start;
+        slab[17 * SK_MAX_C0 + d] = 0;
+        Node o;
+        o.start = start;
+        o.len = cap * n_chunks;
+        o.meta = child_meta;
+        o.split = 0;
+        o.prefix = 0;
+        o.child_base = 0;
+        o.chunk_base = 0;
+        nodes[d] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -495,6 +620,8 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
             m[j] = __builtin_nontemporal_load(&hi[(u64)(i + (u32)j * SK1_NT) * 2]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+            if (m[j] >> 63)
+                continue;                          // (a NULL record: an unused slot of a slab sweep)
             const u32 d1 = (u32)(m[j] >> shift) & (R - 1);
             atomicAdd(&h[d1], 1u);
             atomicAdd(&kc[d1], (u32)((m[j] >> 44) & 31) + 1u);
@@ -502,6 +629,8 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
     }
     for (; i < ch.len; i += SK1_NT) {
         const u64 m = __builtin_nontemporal_load(&hi[(u64)i * 2]);
+        if (m >> 63)
+            continue;
         const u32 d1 = (u32)(m >> shift) & (R - 1);
         atomicAdd(&h[d1], 1u);
         atomicAdd(&kc[d1], (u32)((m >> 44) & 31) + 1u);
@@ -569,7 +698,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
         asm volatile("" : "+v"(tid));              // (thread-derived addresses recomputed per tile, not held: the kernel lives on 64 registers)
-        for (u32 d = tid; d < R; d += SK1_NT)
+        for (u32 d = tid; d <= R; d += SK1_NT)     // (bin R: NULL records -- unused slots of a slab sweep -- sort behind all digits)
             cnt[d] = 0;
         __syncthreads();
         if (n_tile == (u32)SK1_TILE) {
@@ -585,25 +714,27 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             u32 pos[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
-                const u32 dg = (u32)(rec[j].y >> shift) & dmask;
+                const bool null = (rec[j].y >> 63) != 0;
+                const u32 dg = null ? R : (u32)(rec[j].y >> shift) & dmask;
                 pos[j] = atomicAdd(&cnt[dg], 1u);
-                if (SPEC)
+                if (SPEC && !null)
                     atomicAdd(&kcs[dg], (u32)((rec[j].y >> 44) & 31) + 1u);
             }
             __syncthreads();
-            block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
+            block_scan_inplace<SK1_NT>(cnt, (int)R + 1, wtmp);             // cnt -> exclusive offsets; cnt[R] = the tile's records
             u32 got = 0;
             const bool reserve = gc && (u32)tid < R;
             if (reserve) {
-                const u32 c = ((u32)tid + 1 < R ? cnt[tid + 1] : n_tile) - cnt[tid];
+                const u32 c = cnt[tid + 1] - cnt[tid];
                 if (c)
                     got = atomicAdd(&gc[tid], c);
                 if (SPEC && c && (u64)got + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
                     dropped = true;
             }
+            const u32 n_valid = cnt[R];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++)
-                pos[j] += cnt[(u32)(rec[j].y >> shift) & dmask];
+                pos[j] = (rec[j].y >> 63) ? ~0u : pos[j] + cnt[(u32)(rec[j].y >> shift) & dmask];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -616,6 +747,8 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
 #pragma unroll
                 for (int j = 0; j < SK1_ITEMS / 2; j++) {
                     const u32 sl = (u32)h * (SK1_TILE / 2) + tid + j * SK1_NT;
+                    if (sl >= n_valid)
+                        continue;
                     const ull2_t r = stage[tid + j * SK1_NT];
                     const u32 d = (u32)(r.y >> shift) & dmask;
                     // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
@@ -635,16 +768,17 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 rank[j] = 0;
                 if (i < n_tile) {
                     const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
-                    dig[j] = (u32)(m >> shift) & dmask;
+                    const bool null = (m >> 63) != 0;
+                    dig[j] = null ? R : (u32)(m >> shift) & dmask;
                     rank[j] = atomicAdd(&cnt[dig[j]], 1u);
-                    if (SPEC)
+                    if (SPEC && !null)
                         atomicAdd(&kcs[dig[j]], (u32)((m >> 44) & 31) + 1u);
                 }
             }
             __syncthreads();
-            block_scan_inplace<SK1_NT>(cnt, (int)R, wtmp);                 // cnt -> exclusive offsets
+            block_scan_inplace<SK1_NT>(cnt, (int)R + 1, wtmp);             // cnt -> exclusive offsets; cnt[R] = the tile's records
             if (gc && (u32)tid < R) {
-                const u32 c = ((u32)tid + 1 < R ? cnt[tid + 1] : n_tile) - cnt[tid];
+                const u32 c = cnt[tid + 1] - cnt[tid];
                 if (c) {
                     const u32 got = atomicAdd(&gc[tid], c);
                     gpos[tid] = got;
@@ -662,7 +796,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const u32 sl = tid + j * SK1_NT;
-                if (sl < n_tile) {
+                if (sl < cnt[R]) {
                     const ull2_t r = src[t0 + idx[sl]];
                     const u32 d = (u32)(r.y >> shift) & dmask;
                     const u32 p = gpos[d] + (sl - cnt[d]);
@@ -674,10 +808,8 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
         }
         // advance: digit d held (next offset - its offset) records
         if (!gc) {
-            for (u32 d = tid; d < R; d += SK1_NT) {
-                const u32 end = d + 1 < R ? cnt[d + 1] : n_tile;
-                gpos[d] += end - cnt[d];
-            }
+            for (u32 d = tid; d < R; d += SK1_NT)
+                gpos[d] += cnt[d + 1] - cnt[d];
             __syncthreads();
         }
     }
@@ -2070,14 +2202,15 @@ static int sk_dbg()
 // launchers
 template <int W>
 static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk *chunks, const u64 *words, u64 n_words,
-                         u64 first, int k, u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs)
+                         u64 first, int k, u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs,
+                         u32 *aux)
 {
     if (scatter)
         hipLaunchKernelGGL(sk_scatter0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           k, lmax, mmask, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg());
+                           k, lmax, mmask, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg(), aux);
     else
         hipLaunchKernelGGL(sk_hist0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           lmax, mmask, c0n, b1mask, r0n, hist);
+                           lmax, mmask, c0n, b1mask, r0n, hist, aux);
 }
 
 // The minimizer's length m: 15 for k >= 23 (windows of 9 .. 18 m-mers), 13 for k = 21 and 22 (windows of 9 and 10: runs of
@@ -2087,7 +2220,7 @@ int sk_min_k() { return 21; }
 int sk_minimizer_len(int k) { return k >= 23 ? 15 : 13; }
 
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
-                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s)
+                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s, u32 *aux)
 {
     if (n_chunks == 0)
         return hipSuccess;
@@ -2100,12 +2233,30 @@ hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, con
     const u32 b1mask = (1u << b1bits) - 1, r0n = 1u << r0bits;
     if (r0n > (u32)SK_MAX_C0)
         return hipErrorInvalidValue;
-#define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs); break;
+#define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs, aux); break;
     switch (w) {
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16) SK_CASE(17) SK_CASE(18)
     default: return hipErrorInvalidValue;
     }
 #undef SK_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_sk_sample_chunks(Chunk *chunks, u32 n_chunks, u32 stride, u32 len, u32 n, hipStream_t s)
+{
+    if (n_chunks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sk_sample_chunks_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, s, chunks, n_chunks, stride, len, n);
+    return hipGetLastError();
+}
+
+int sk_slab_words() { return 18 * SK_MAX_C0 + 4; }
+
+hipError_t launch_sk_slab_init(const u32 *est, u32 r0bits, u32 chunk_rows, u32 sampled, u32 n_chunks, u32 *slab, Node *nodes,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(sk_slab_init_kernel, dim3(1), dim3(SK_MAX_C0), 0, s, est, 1u << r0bits, chunk_rows, sampled, n_chunks,
+                       (u32)(32 - r0bits), slab, nodes);
     return hipGetLastError();
 }
 

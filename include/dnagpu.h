@@ -395,6 +395,14 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * path; DNAGPU_DEBUG_SPEC1_OVERFLOW runs the speculative sweep and then treats it as overflowed (tests of the fall-back). */
 #define DNAGPU_DEBUG_NO_SPEC1 16u
 #define DNAGPU_DEBUG_SPEC1_OVERFLOW 32u
+/* Level 0 likewise runs WITHOUT its histogram sweep on long sequences (from 2^29 rows): a histogram over 1/64 of the rows
+ * sizes, per coarse bucket, the slots every chunk of rows reserves in the bucket's region; slots a chunk does not use
+ * hold NULL records, which level 1 skips; a chunk that runs out of slots (or uneven buckets in the sample: repeats) sends
+ * the level through the exact pair (histogram sweep, prefix, scatter sweep).  DNAGPU_DEBUG_SLAB0 takes the slab sweep for
+ * every length, DNAGPU_DEBUG_NO_SLAB0 never, DNAGPU_DEBUG_SLAB0_OVERFLOW runs it and then treats it as overflowed. */
+#define DNAGPU_DEBUG_SLAB0 64u
+#define DNAGPU_DEBUG_NO_SLAB0 128u
+#define DNAGPU_DEBUG_SLAB0_OVERFLOW 256u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

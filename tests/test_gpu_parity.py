@@ -699,6 +699,48 @@ def test_level1_speculative_and_exact_agree(ctx, pkg, n, k, kind):
     d.free()
 
 
+@pytest.mark.parametrize("n,k,kind", [(3_000_000, 31, "random"), (5_000_001, 25, "sample misses"), (20_000_000, 27, "random"),
+                                      (6_000_000, 21, "motif"), (70_000, 31, "random")])
+def test_level0_slabs_and_exact_agree(ctx, pkg, n, k, kind):
+    """level 0 of the record engine without its histogram sweep (chunks reserve slabs sized from a sampled histogram; the
+    default from 2^29 rows, forced here), the exact pair (DNAGPU_DEBUG_NO_SLAB0) and the fall-back -- forced
+    (DNAGPU_DEBUG_SLAB0_OVERFLOW) and real (the sampled windows are poly-A, which makes few records, the rest is random:
+    the slabs are far too small and the chunks run out of slots) -- all give the oracle's groups"""
+    if kind == "motif":
+        words = orc.synth_words_repeat(0xC0DE + n, n, 500)
+    else:
+        words = orc.synth_words(0xC0DE + n, n)
+    if kind == "sample misses":                      # the sample: four histogram tiles (4 x 8064 rows) every 64 x that many rows
+        span = 4 * 8064
+        for lo in range(0, n, 64 * span):
+            words[lo // 32:(lo + span) // 32 + 2] = np.uint64(0)
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False))
+    ctx.set_profiling(True)
+    for name, flag in (("slabs", pkg.DEBUG_SLAB0), ("exact", pkg.DEBUG_NO_SLAB0), ("overflow forced", pkg.DEBUG_SLAB0_OVERFLOW)):
+        ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | flag)
+        try:
+            h = ctx.count_kmers_unordered(d, k)
+        finally:
+            ctx.set_debug(0)
+        phases = {a for a, _ in ctx.last_phase_times()}
+        assert not h.is_sorted
+        check_hist_unordered(h, ok, oc, f"level 0 {name}: n={n} k={k} {kind}")
+        h.free()
+        # which way level 0 went: the sample + slab sweep alone on random sequence; followed by the exact pair ("sk_hist0")
+        # where the chunks ran out of slots or the test flag says so; the exact pair alone when asked
+        if name == "exact":
+            assert "sk_sample0" not in phases and "sk_hist0" in phases, phases
+        else:
+            assert "sk_sample0" in phases, phases
+            if kind == "random" and name == "slabs":
+                assert "sk_hist0" not in phases, phases
+            if name == "overflow forced" or kind == "sample misses":
+                assert "sk_hist0" in phases, (name, kind, phases)
+    ctx.set_profiling(False)
+    d.free()
+
+
 @pytest.mark.parametrize("kind", ["motif1000", "motif37", "motif100000", "polyA", "half-polyA", "quarter-polyA", "AT",
                                   "small-polyA", "small-AT"])
 @pytest.mark.parametrize("k", [31, 21])

@@ -57,6 +57,8 @@ with pkg.Context(0) as ctx:
         flags = int(rng.choice([pkg.DEBUG_FORCE_SUPERKMER, pkg.DEBUG_FORCE_SUPERKMER, pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_HEAVY_EXPAND]))
         # level 1: speculative regions (the default; repeats overflow them and fall back), the exact level, the forced fall-back
         flags |= int(rng.choice([0, 0, pkg.DEBUG_NO_SPEC1, pkg.DEBUG_SPEC1_OVERFLOW]))
+        # level 0: slabs from a sampled histogram (forced: the sequences here are short), the exact pair, the forced fall-back
+        flags |= int(rng.choice([pkg.DEBUG_SLAB0, pkg.DEBUG_SLAB0, pkg.DEBUG_NO_SLAB0, pkg.DEBUG_SLAB0_OVERFLOW]))
         ctx.set_debug(flags)
         try:
             h = ctx.count_kmers_unordered(d, k, first, count)
