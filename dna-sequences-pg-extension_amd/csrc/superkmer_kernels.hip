@@ -10,9 +10,13 @@
 //              average, never more than SK_LMAX): 16 bytes = up to 54 bases (108 bits) + length + d1 + d2
 //
 //   sk_hist0 / sk_scatter0   sweep the packed dna: hashes, window minima, runs -> records scattered
-//                            into C0 coarse buckets (1.8 B per k-mer instead of 8)
-//   sk_hist1 / sk_scatter1   records of a coarse bucket -> 2^b1 mid buckets
-//   sk_regroup               a mid bucket's records regrouped by d2: 16 final buckets of ~2,900 k-mers
+//                            into C0 coarse buckets (1.8 B per k-mer instead of 8).  Long sequences: the scatter sweep
+//                            alone, every chunk of rows reserving slabs sized from a sampled histogram (unused slots =
+//                            NULL records, bit 63 of the second word, dropped by level 1); the exact pair is the fall-back
+//   sk_hist1 / sk_scatter1   records of a coarse bucket -> 2^b1 mid buckets, every record read once; normally without
+//                            the histogram: mid buckets are regions sized from their parent, tiles reserve slots from
+//                            global cursors (sk_spec_*), the exact level is the fall-back
+//   sk_regroup               a mid bucket's records regrouped by d2 (read once): 16 final buckets of ~2,700 k-mers
 //   sk_count                 a final bucket counted from its records in an LDS hash table (fingerprint slots); its groups go
 //                            to its own output range
 //   sk_count_big / sk_big_merge   long final buckets of few distinct keys (repeats): one table per bucket, slices of records
