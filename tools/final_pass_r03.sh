@@ -31,8 +31,8 @@ echo "pmc done"
 timeout -k 10 300 python3 tools/records_probe.py 3e9 31 1,2,4,8 350 > $O/records_probe.log 2>&1
 timeout -k 10 120 python3 tools/overhead_probe.py > $O/overhead_probe.log 2>&1
 echo "probes done"
-timeout -k 10 600 python3 tools/fuzz_unordered.py 2500 > $O/fuzz_unordered.log 2>&1; tail -1 $O/fuzz_unordered.log
-timeout -k 10 300 python3 tools/fuzz_count.py 600 > $O/fuzz_count.log 2>&1; tail -1 $O/fuzz_count.log
+timeout -k 10 600 python3 tools/fuzz_unordered.py ${FUZZ_U:-2500} > $O/fuzz_unordered.log 2>&1; tail -1 $O/fuzz_unordered.log
+timeout -k 10 300 python3 tools/fuzz_count.py ${FUZZ_C:-600} > $O/fuzz_count.log 2>&1; tail -1 $O/fuzz_count.log
 if [ "$2" = "suite" ]; then
   timeout -k 10 900 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
   DNAGPU_TEST_POISON=1 timeout -k 10 900 python3 -m pytest tests -q -m gpu > $O/pytest_gpu_poison.log 2>&1; echo "rc=$?" >> $O/pytest_gpu_poison.log; tail -3 $O/pytest_gpu_poison.log
