@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--launcher", choices=["one-process", "torchrun"], default="one-process",
                     help="--gpus N > 1 without WORLD_SIZE in the environment: one-process = this process drives all N GPUs "
                          "through the C-ABI (default); torchrun = spawn torch.distributed.run as a child, one process per GPU")
+    ap.add_argument("--exchange", choices=["copy", "rccl"], default="copy",
+                    help="one-process path, record exchange: copy = owners pull with peer copies (default), rccl = "
+                         "ncclSend / ncclRecv per piece (needs distinct devices and librccl)")
     ap.add_argument("--parts", type=int, default=0,
                     help="one-process path: bucket groups per owner of the pipelined record exchange (0 = library default)")
     ap.add_argument("--emulate-link-gbs", type=float, default=0.0,
@@ -237,6 +240,26 @@ def main():
         dist.all_reduce(dsum)
         distinct[0] = int(dsum.item())
 
+    # ---- outside the timed region: one more count whose histogram is digested on the device and compared with the CPU
+    # oracle's digest of the same workload (every rank's share summed: the histograms are disjoint)
+    digest = None
+    if not is_filter:
+        if world == 1:
+            hv = count_fn(dna, k)
+        elif use_records:
+            hv, state["chunk"] = sh.count_sharded_exchange_records(engine, seed, n_bases, k, rank, world, state["chunk"],
+                                                                   parts=max(args.parts, 1))
+        else:
+            hv, state["chunk"] = sh.count_sharded(engine, seed, n_bases, k, rank, world, state["chunk"])
+        mine = [int(x) & 0xFFFFFFFFFFFFFFFF for x in hv.summary()]
+        hv.free()
+        if dist is not None:
+            # (int64 tensors: the checksum's wrapping sum is reassembled from two 32-bit halves)
+            parts_ = torch.tensor([[v >> 32, v & 0xFFFFFFFF] for v in mine], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(parts_)
+            mine = [((int(hi) << 32) + int(lo)) & 0xFFFFFFFFFFFFFFFF for hi, lo in parts_.tolist()]
+        digest = digest_check(args.config, n_bases, k, seed, args.motif, mine)
+
     if rank == 0 and world == 1 and not is_filter and not sorted_result[0]:
         extra["sorted_view_ms"] = None
         extra["group_order"] = ("unspecified (bucket order of the super-k-mer engine; PostgreSQL's GROUP BY order is "
@@ -326,6 +349,13 @@ def main():
             "phases_ms": {n_: round(m, 4) for n_, m in means.items()},
         }
         line.update(extra)
+        if digest is not None:
+            line.update(digest)
+        if world > 1:
+            line["launcher"] = "torchrun"
+            line["exchange_transport"] = (f"{dist.get_backend()} " + ("all_to_all_single" if use_records and max(args.parts, 1) == 1 else
+                                          ("batch_isend_irecv" if use_records else "all_gather")))
+            line["rccl_ranks"] = world if dist.get_backend() == "nccl" else 0
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_filter(cfg, seed) if is_filter else cpu_baseline(k, seed)
         print(json.dumps(line), flush=True)
@@ -334,6 +364,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if digest is not None and digest_failed(digest):
+        raise SystemExit(3)                       # the groups differ from the CPU oracle's: the number above is void
 
 
 def spawn_torchrun(n_gpus):
@@ -402,6 +434,8 @@ def main_one_process(args):
     mdna = multi.synth(seed, n_bases)
     use_records = args.engine != "tree" and k >= 21
     count_fn = multi.count_unordered if use_records else multi.count
+    if args.exchange == "rccl":
+        multi.set_exchange_rccl(1)                 # (fails loudly when no communicator exists: shared devices, no librccl)
 
     def sync_all():
         for c in multi.ranks:
@@ -414,8 +448,8 @@ def main_one_process(args):
         hs = count_fn(mdna, k)
         distinct[0] = sum(h.distinct for h in hs)
         per_step = {}                              # (the pipelined exchange counts an owner's buckets group by group: a phase
-        for name, ms in multi.ranks[0].last_phase_times():   # name then appears once per group -- their SUM is the step's)
-            per_step[name] = per_step.get(name, 0.0) + ms
+        for name, ms in (multi.rank_phase_times(0) if use_records else multi.ranks[0].last_phase_times()):
+            per_step[name] = per_step.get(name, 0.0) + ms      # (... name then appears once per group: their SUM is the step's)
         for name, ms in per_step.items():
             phases_acc.setdefault(name, []).append(ms)
         if use_records:
@@ -435,6 +469,17 @@ def main_one_process(args):
     sync_all()
     elapsed = time.perf_counter() - t0
 
+    # outside the timed region: one more count, every rank's histogram digested on its device, the sums against the CPU
+    # oracle's digest of the same workload
+    hs = count_fn(mdna, k)
+    sums = [0, 0, 0, 0]
+    for h in hs:
+        for i, v in enumerate(h.summary()):
+            sums[i] = (sums[i] + int(v)) & 0xFFFFFFFFFFFFFFFF
+        h.free()
+    digest = digest_check(args.config, n_bases, k, seed, 0, sums)
+    exchange_transport = multi.exchange_transport
+
     ms_per_step = elapsed / args.steps * 1e3
     t_step = elapsed / args.steps
     value = n_kmers * args.steps / elapsed
@@ -453,8 +498,10 @@ def main_one_process(args):
     xm = {name: sum(v) / len(v) for name, v in xacc.items()}
     exchange = None
     if use_records:
-        exchange = {"what": "records: own rows -> super-k-mer records -> owners pull their coarse buckets (peer copies of "
-                            "16-byte records) -> counted group by group while later groups are in flight",
+        exchange = {"what": "records: own rows -> super-k-mer records -> every coarse bucket's pieces to its owner ("
+                            + ("one ncclSend / ncclRecv per piece, a group call per bucket group" if exchange_transport == "rccl-sendrecv"
+                               else "the owner pulls them: peer copies of 16-byte records")
+                            + ") -> counted group by group while later groups are in flight",
                     "parts": int(xm.get("parts", 0)), "records_ms": round(xm.get("records_ms", 0), 3),
                     "exchange_ms": round(xm.get("exchange_ms", 0), 3), "hidden_ms": round(xm.get("hidden_ms", 0), 3),
                     "owners_ms": round(xm.get("count_ms", 0), 3), "call_ms": round(xm.get("total_ms", 0), 3),
@@ -465,14 +512,20 @@ def main_one_process(args):
     line = {
         "metric": HEADLINE_METRIC if (args.config == 4 and n_bases == CONFIGS[4]["n_bases"] and k == CONFIGS[4]["k"]) else
         f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline",
-        "value": value, "unit": "k-mers/s", "n_gpus": W, "steps": args.steps, "warmup": args.warmup,
+        # (a rehearsal -- ranks sharing devices -- reports the devices it really used, so that the line cannot be read as
+        # a scaling point; "ranks" is always the N that was asked for)
+        "value": value, "unit": "k-mers/s", "n_gpus": len(set(devices)), "ranks": W, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}), "
                                f"sharded by contiguous chunk over {W} ranks driven by one process through the C-ABI "
                                f"(dnagpu_count_multi{'_unordered' if use_records else ''})",
                    "n_bases": n_bases, "k": k, "distinct": distinct[0]},
-        "launcher": "one-process", "devices": devices, "transport": multi.transport, "rehearsal": rehearsal,
+        "launcher": "one-process", "devices": devices, "distinct_devices": len(set(devices)),
+        # what the timed path moved its data with -- NOT what is merely available (rccl_available)
+        "exchange_transport": exchange_transport,
+        "rccl_ranks": multi.rccl_ranks if exchange_transport.startswith("rccl") else 0,
+        "rccl_available": multi.transport == "rccl", "rehearsal": rehearsal,
         "roofline": roofline,
         "job_roofline": job_fractions(b_in, distinct[0], n_kmers, t_step, W),
         "phases_ms": {n_: round(m, 4) for n_, m in means.items()},
@@ -481,9 +534,53 @@ def main_one_process(args):
     if rehearsal:
         line["rehearsal_note"] = (f"{W} ranks share {n_dev} device(s): the code path of the N-GPU run (chunk residency, halo "
                                   "word, per-rank records, owners' pulls, pipelined count), NOT a scaling measurement")
+    line.update(digest)
     print(json.dumps(line), flush=True)
     multi.dna_free(mdna)
     multi.close()
+    if digest_failed(digest):
+        raise SystemExit(3)                       # the groups differ from the CPU oracle's: the number above is void
+
+
+def digest_key(config, n_bases, k, motif):
+    """key of tests/golden/config_digests.json for this workload, or None when the oracle never counted it"""
+    base = CONFIGS.get(config)
+    if not base or base["kind"] != "count" or n_bases != base["n_bases"] or k != base["k"]:
+        return None
+    return f"{config}m{motif}" if motif else str(config)
+
+
+def digest_check(config, n_bases, k, seed, motif, got):
+    """got = (total, distinct, unique, checksum) summed over the ranks' histograms (dnagpu_hist_summary: the checksum is a
+    wrapping sum over groups, so disjoint histograms add up).  Compared with the CPU oracle's digest of the same workload
+    (tools/make_digests.py -> tests/golden/config_digests.json).  -> the fields for the JSON line; digest_ok is None when
+    the oracle holds no digest for this workload (then only total == rows is checked: digest_total_ok)."""
+    total, distinct, unique, checksum = (int(x) for x in got)
+    out = {"digest": {"total": total, "distinct": distinct, "unique": unique, "checksum": checksum}}
+    out["digest_total_ok"] = total == n_bases - k + 1
+    key = digest_key(config, n_bases, k, motif)
+    want = None
+    if key is not None:
+        try:
+            # (BENCH_DIGESTS: the test of this check points it at a doctored copy to see it fail)
+            with open(os.environ.get("BENCH_DIGESTS") or os.path.join(ROOT, "tests", "golden", "config_digests.json")) as f:
+                want = json.load(f).get(key)
+        except Exception:
+            want = None
+    if want is None or int(want["seed"]) != seed:
+        out["digest_ok"] = None
+        out["digest_source"] = "no oracle digest for this workload: only sum(count) == rows was checked"
+        return out
+    out["digest_ok"] = all(int(want[f]) == v for f, v in
+                           (("total", total), ("distinct", distinct), ("unique", unique), ("checksum", checksum)))
+    out["digest_source"] = f"tests/golden/config_digests.json[{key!r}] (CPU oracle, tools/make_digests.py)"
+    if not out["digest_ok"]:
+        out["digest_expected"] = {f: int(want[f]) for f in ("total", "distinct", "unique", "checksum")}
+    return out
+
+
+def digest_failed(d):
+    return d.get("digest_ok") is False or d.get("digest_total_ok") is False
 
 
 def job_fractions(b_in, distinct, n_kmers, t_step, world):

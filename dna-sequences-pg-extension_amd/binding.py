@@ -174,6 +174,10 @@ def lib():
     L.dnagpu_device_count.restype = C.c_int
     L.dnagpu_multi_set_option.argtypes = [vp, C.c_int, C.c_double]
     L.dnagpu_multi_last_times.argtypes = [vp, C.POINTER(_MultiTimes)]
+    L.dnagpu_multi_exchange_transport.argtypes = [vp]
+    L.dnagpu_multi_exchange_transport.restype = C.c_char_p
+    L.dnagpu_multi_rccl_ranks.argtypes = [vp]
+    L.dnagpu_multi_last_phase_times.argtypes = [vp, C.c_int, C.POINTER(_PhaseTimes)]
     L.dnagpu_hist_parts.argtypes = [vp]
     L.dnagpu_hist_parts.restype = C.c_uint32
     L.dnagpu_hist_part.argtypes = [vp, C.c_uint32]
@@ -590,7 +594,7 @@ class Context:
 
 
 MULTI_AUTO, MULTI_RCCL, MULTI_COPY = 0, 1, 2
-MULTI_OPT_PARTS, MULTI_OPT_EMULATE_LINK_GBS, MULTI_OPT_PROBE_OWNER = 1, 2, 3
+MULTI_OPT_PARTS, MULTI_OPT_EMULATE_LINK_GBS, MULTI_OPT_PROBE_OWNER, MULTI_OPT_EXCHANGE_RCCL = 1, 2, 3, 4
 
 
 class _BorrowedContext(Context):
@@ -622,6 +626,25 @@ class Multi:
     @property
     def transport(self):
         return lib().dnagpu_multi_transport(self.h).decode()
+
+    @property
+    def exchange_transport(self):
+        """what the most recent count moved its data between ranks with ("peer-copy", "rccl-sendrecv", ...)"""
+        return lib().dnagpu_multi_exchange_transport(self.h).decode()
+
+    @property
+    def rccl_ranks(self):
+        return int(lib().dnagpu_multi_rccl_ranks(self.h))
+
+    def set_exchange_rccl(self, mode):
+        """record exchange of count_unordered: 0 = peer copies, 1 = ncclSend / ncclRecv, 2 = own pieces through RCCL too"""
+        _chk(lib().dnagpu_multi_set_option(self.h, MULTI_OPT_EXCHANGE_RCCL, float(mode)))
+
+    def rank_phase_times(self, rank):
+        """device phases of rank `rank` in the most recent count_unordered: its record pass, then its owner phase"""
+        pt = _PhaseTimes()
+        _chk(lib().dnagpu_multi_last_phase_times(self.h, rank, C.byref(pt)))
+        return [(pt.names[i].decode(), float(pt.ms[i])) for i in range(pt.n)]
 
     def set_parts(self, parts):
         """bucket groups per owner of count_unordered's pipelined exchange (1 = no overlap)"""

@@ -239,16 +239,23 @@ __global__ __launch_bounds__(1024) void plan_small_kernel(Node *__restrict__ nod
     }
 }
 
+// experiment (diagnostic build): cap the split width of levels >= 1.  Initialised once, thread-safe (the rank threads of
+// dnagpu_count_multi* plan concurrently)
+static int plan_l1_cap()
+{
+    static const int cap = [] {
+        const char *e = diag_env("DNAGPU_L1_BITS");
+        return e ? atoi(e) : MAX_SPLIT_BITS;
+    }();
+    return cap;
+}
+
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
                        LevelCounters *ctr, hipStream_t s)
 {
     if (n_nodes == 0)
         return hipSuccess;
-    static int l1_cap = 0;
-    if (l1_cap == 0) {
-        const char *e = diag_env("DNAGPU_L1_BITS");         // experiment: cap the split width of levels >= 1
-        l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
-    }
+    const int l1_cap = plan_l1_cap();
     if (level >= 2)
         hipLaunchKernelGGL(plan_count_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, ctr);
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
@@ -262,11 +269,7 @@ hipError_t launch_plan_level(Node *nodes, u32 n_nodes, int level, u32 chunk_len,
                              LevelCounters *ctr, hipStream_t s)
 {
     if (n_nodes > 0 && n_nodes <= 1024) {
-        static int l1_cap = 0;
-        if (l1_cap == 0) {
-            const char *e = diag_env("DNAGPU_L1_BITS");
-            l1_cap = e ? atoi(e) : MAX_SPLIT_BITS;
-        }
+        const int l1_cap = plan_l1_cap();
         hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, s, nodes, n_nodes, level, chunk_len, outc, nch, ctr, l1_cap);
         return hipGetLastError();
     }

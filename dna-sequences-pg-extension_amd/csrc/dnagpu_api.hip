@@ -2715,7 +2715,9 @@ extern "C" int dnagpu_partition_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, in
 // over xGMI, or peer copies), then every rank counts the key range it owns in its own host thread.
 // Same algorithm and ownership rule as the process-per-GPU path of sharded.py (bench.py --gpus N).
 #include <dlfcn.h>
+#include <pthread.h>
 #include <rccl/rccl.h>
+#include <signal.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -2731,6 +2733,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -2750,10 +2754,12 @@ struct RcclApi {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
         Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !AllGather || !Reduce || !GroupStart || !GroupEnd || !GetErrorString) {
+        if (!CommInitAll || !CommDestroy || !AllGather || !Reduce || !Send || !Recv || !GroupStart || !GroupEnd || !GetErrorString) {
             dlclose(lib);
             lib = nullptr;
             return false;
@@ -2815,6 +2821,13 @@ struct MultiPool {
         if (started)
             return;
         started = true;
+        // The workers must never run the host program's signal handlers: a PostgreSQL backend's handlers (SIGINT cancel,
+        // SIGUSR1 latch, SIGTERM) are not thread-safe, and the kernel may deliver a process-directed signal to ANY thread
+        // that does not block it.  Threads inherit the creating thread's mask: every signal is blocked around the creation
+        // and the caller's mask restored right after, so the workers block everything for their whole life.
+        sigset_t all, old_mask;
+        sigfillset(&all);
+        const bool masked = pthread_sigmask(SIG_BLOCK, &all, &old_mask) == 0;
         try {
             threw.assign((size_t)n, 0);
             th.reserve((size_t)n);
@@ -2824,6 +2837,8 @@ struct MultiPool {
             shutdown();                       // joins the threads that did start
             serial = true;
         }
+        if (masked)
+            (void)pthread_sigmask(SIG_SETMASK, &old_mask, nullptr);
     }
     // runs f(r) for r = 0 .. n-1, rank 0 here; returns 0, or DNAGPU_ERR_OOM / DNAGPU_ERR_INTERNAL if a job threw
     int run(int n, const std::function<void(int)> &f) noexcept
@@ -2877,6 +2892,10 @@ struct dnagpu_multi {
     int parts = DNAGPU_MULTI_DEFAULT_PARTS;   // bucket groups per owner of the pipelined exchange
     double emulate_gbs = 0;               // rehearsal: same-device "transfers" are held to this rate (0 = off)
     int probe_owner = -1;                 // rehearsal: only this owner pulls and counts (-1 = all), so that its time is its own
+    int exchange_rccl = 0;                // record exchange: 0 = owners pull with peer copies, 1 = ncclSend / ncclRecv per piece,
+                                          // 2 = as 1 and a rank's own pieces travel through RCCL too (tests with one rank)
+    const char *last_exchange = "none";   // what the most recent dnagpu_count_multi_unordered moved its records with
+    std::vector<dnagpu_phase_times> rec_phases;   // per rank: device phases of its record pass (most recent unordered count)
 };
 
 struct dnagpu_multi_dna {
@@ -2994,6 +3013,26 @@ extern "C" dnagpu_ctx *dnagpu_multi_ctx(dnagpu_multi *m, int rank)
     return (m && rank >= 0 && rank < m->n) ? m->ctx[(size_t)rank] : nullptr;
 }
 extern "C" const char *dnagpu_multi_transport(const dnagpu_multi *m) { return !m ? "" : (m->rccl ? "rccl" : "copy"); }
+extern "C" const char *dnagpu_multi_exchange_transport(const dnagpu_multi *m) { return !m ? "" : m->last_exchange; }
+extern "C" int dnagpu_multi_rccl_ranks(const dnagpu_multi *m) { return (m && m->rccl) ? m->n : 0; }
+extern "C" int dnagpu_multi_last_phase_times(dnagpu_multi *m, int rank, dnagpu_phase_times *out)
+{
+    if (!m || !out || rank < 0 || rank >= m->n)
+        return DNAGPU_ERR_BAD_ARG;
+    // the record pass's phases (kept by the call: the owner phase starts a new session on the rank's context), then the
+    // owner phase's
+    dnagpu_phase_times t{};
+    if ((size_t)rank < m->rec_phases.size())
+        t = m->rec_phases[(size_t)rank];
+    const dnagpu_phase_times &o = m->ctx[(size_t)rank]->last_times;
+    for (int i = 0; i < o.n && t.n < DNAGPU_MAX_PHASES; i++) {
+        t.names[t.n] = o.names[i];
+        t.ms[t.n] = o.ms[i];
+        t.n++;
+    }
+    *out = t;
+    return DNAGPU_OK;
+}
 extern "C" int dnagpu_multi_last_times(const dnagpu_multi *m, dnagpu_multi_times *out)
 {
     if (!m || !out)
@@ -3280,8 +3319,11 @@ extern "C" int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, 
     for (int r = 0; r < m->n; r++)
         hists[r] = nullptr;
     RC_TRY(check_range(dna->view[0], k, first, count));
-    if (dense_pays(count, k))
+    if (dense_pays(count, k)) {
+        m->last_exchange = m->n == 1 ? "none" : (m->rccl ? "rccl-reduce" : "peer-copy");
         return multi_count_dense(m, dna, k, first, count, hists);
+    }
+    m->last_exchange = m->n == 1 ? "none" : (m->rccl ? "rccl-allgather" : "peer-copy");
     RC_TRY(multi_gather(m, dna));
     // one host thread per rank: the level loop of a count reads counters back between levels, so the ranks
     // only run concurrently when each is driven by its own thread (device selection is per thread)
@@ -3352,6 +3394,15 @@ extern "C" int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value
         if (value < -1 || value >= m->n)
             return DNAGPU_ERR_BAD_ARG;
         m->probe_owner = (int)value;
+        return DNAGPU_OK;
+    case DNAGPU_MULTI_OPT_EXCHANGE_RCCL:
+        if (value < 0 || value > 2)
+            return DNAGPU_ERR_BAD_ARG;
+        if (value > 0 && !m->rccl) {
+            set_err("the RCCL record exchange needs the RCCL transport (dnagpu_multi_transport() is \"%s\")", m->rccl ? "rccl" : "copy");
+            return DNAGPU_ERR_BAD_ARG;
+        }
+        m->exchange_rccl = (int)value;
         return DNAGPU_OK;
     }
     return DNAGPU_ERR_BAD_ARG;
@@ -3425,8 +3476,10 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
                                            count, &recs[(size_t)r]);
         if (rcs[(size_t)r] != DNAGPU_OK)
             errs[(size_t)r] = dnagpu_last_error();
+        m->rec_phases[(size_t)r] = c->last_times;  // (the owner phase below starts a new profiling session on this context)
         t_rec[(size_t)r] = ms_since(t0);
     };
+    m->rec_phases.assign((size_t)W, dnagpu_phase_times{});
     int rc = m->workers.run(W, cut);
     if (rc != DNAGPU_OK)
         set_err("a rank's record pass ended in a C++ exception");
@@ -3508,6 +3561,14 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
             }
         }
         m->last.parts = P;
+        // How the remote pieces travel.  Default: the owner PULLS every piece with a peer copy on its transfer stream.
+        // DNAGPU_MULTI_OPT_EXCHANGE_RCCL: every piece is one ncclSend on its rank's transfer stream and one ncclRecv on its
+        // owner's, a group call per bucket group (round p: a rank sends what the other owners' groups p hold of its records
+        // and receives its own group p; between two ranks the pieces are issued in ascending bucket order on both sides).
+        // Needs every rank driven by its own thread (the ranks' group calls meet each other) and all owners active.
+        const bool via_rccl = m->exchange_rccl > 0 && m->rccl && !m->workers.serial && m->probe_owner < 0;
+        const bool rccl_self = via_rccl && m->exchange_rccl == 2;
+        m->last_exchange = via_rccl ? "rccl-sendrecv" : "peer-copy";
         const std::function<void(int)> own = [&](int o) {
             const auto t0 = std::chrono::steady_clock::now();
             dnagpu_ctx *c = m->ctx[(size_t)o];
@@ -3577,7 +3638,49 @@ extern "C" int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_
             for (int p = 0; p < P; p++) {
                 const u32 b_lo = cuts[(size_t)o * P + p], b_hi = std::max(cuts[(size_t)o * P + p + 1], b_lo);
                 const std::vector<u64> &boff = boffs[(size_t)p];
-                if (bufs[(size_t)p]) {
+                if (via_rccl) {
+                    ncclResult_t nr = m->api.GroupStart();
+                    // this rank's records of the other owners' groups p (its own pieces too when asked: one-rank tests)
+                    const dnagpu_records *mine = recs[(size_t)o];
+                    for (int q = 0; q < W && nr == ncclSuccess; q++) {
+                        const int dst = (o + q) % W;
+                        if (dst == o && !rccl_self)
+                            continue;
+                        const u32 d_lo = cuts[(size_t)dst * P + p], d_hi = std::max(cuts[(size_t)dst * P + p + 1], d_lo);
+                        for (u32 b = d_lo; b < d_hi && nr == ncclSuccess; b++) {
+                            const u64 n_b = mine->off[b + 1] - mine->off[b];
+                            if (n_b)
+                                nr = m->api.Send(static_cast<const char *>(mine->recs) + mine->off[b] * 16, (size_t)n_b * 2, ncclUint64,
+                                                 dst, m->comms[(size_t)o], xs);
+                        }
+                    }
+                    for (u32 b = b_lo; b < b_hi && nr == ncclSuccess && bufs[(size_t)p]; b++) {
+                        u64 at = boff[b];
+                        for (int q = 0; q < W && nr == ncclSuccess; q++) {
+                            const int src = (o + q) % W;
+                            const dnagpu_records *rr = recs[(size_t)src];
+                            const u64 n_b = rr->off[b + 1] - rr->off[b];
+                            if (!n_b)
+                                continue;
+                            char *to = static_cast<char *>(bufs[(size_t)p]) + at * 16;
+                            if (src == o && !rccl_self) {
+                                if (hipMemcpyAsync(to, static_cast<const char *>(rr->recs) + rr->off[b] * 16, (size_t)n_b * 16,
+                                                   hipMemcpyDeviceToDevice, xs) != hipSuccess)
+                                    nr = ncclUnhandledCudaError;
+                            } else {
+                                nr = m->api.Recv(to, (size_t)n_b * 2, ncclUint64, src, m->comms[(size_t)o], xs);
+                                if (src != o)
+                                    moved[(size_t)o] += n_b * 16;
+                            }
+                            at += n_b;
+                        }
+                    }
+                    const ncclResult_t ne = m->api.GroupEnd();
+                    if (nr != ncclSuccess || ne != ncclSuccess) {
+                        (void)hipGetLastError();
+                        return drop(DNAGPU_ERR_HIP, m->api.GetErrorString(nr != ncclSuccess ? nr : ne));
+                    }
+                } else if (bufs[(size_t)p]) {
                     u64 delay_bytes = 0;
                     for (u32 b = b_lo; b < b_hi; b++) {
                         u64 at = boff[b];

@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define DNAGPU_ABI_VERSION 1
+/* 2: histograms of several parts (dnagpu_hist_parts: what dnagpu_count_multi_unordered returns with its default of three
+ * bucket groups per owner -- dnagpu_hist_device_keys / _counts are NULL for those), the dnagpu_multi_* options, the
+ * table-of-sequences count (dnagpu_count_kmers_batch, dnagpu_hist_merge) */
+#define DNAGPU_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------
  * 1..3 are the reference's own ERROR conditions on this path; dnagpu_strerror() returns the
@@ -298,7 +301,16 @@ int dnagpu_multi_init(const int *devices, int n_gpus, int transport, dnagpu_mult
 void dnagpu_multi_destroy(dnagpu_multi *m);
 int dnagpu_multi_size(const dnagpu_multi *m);
 dnagpu_ctx *dnagpu_multi_ctx(dnagpu_multi *m, int rank);
-const char *dnagpu_multi_transport(const dnagpu_multi *m);   /* "rccl" or "copy" */
+/* "rccl" when the communicator exists (ncclCommInitAll succeeded: the ordered paths' all-gather / reduce use it, and the
+ * record exchange can, see DNAGPU_MULTI_OPT_EXCHANGE_RCCL), else "copy".  This says what is AVAILABLE; what a count actually
+ * moved its data with is dnagpu_multi_exchange_transport. */
+const char *dnagpu_multi_transport(const dnagpu_multi *m);
+/* How the most recent dnagpu_count_multi / dnagpu_count_multi_unordered call on m moved data between ranks: "peer-copy"
+ * (hipMemcpyPeerAsync pulls; plain device copies when ranks share a device), "rccl-sendrecv" (the record exchange through
+ * ncclSend / ncclRecv), "rccl-allgather" / "rccl-reduce" (the ordered paths), "none" (one rank, or no call yet). */
+const char *dnagpu_multi_exchange_transport(const dnagpu_multi *m);
+/* ranks of the RCCL communicator (0 when there is none) */
+int dnagpu_multi_rccl_ranks(const dnagpu_multi *m);
 
 /* The packed sequence sharded by contiguous word chunk: rank r is resident with words
  * [r*per, (r+1)*per), per = ceil(ceil(n_bases/32) / n).  upload: from the host words of dna->bit_sequence
@@ -339,12 +351,20 @@ int dnagpu_count_multi_unordered(dnagpu_multi *m, const dnagpu_multi_dna *dna, i
  *   DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  rehearsal aid for ranks that share one device: every group of inbound pieces is
  *                                      followed, on the transfer stream, by the time the same bytes would take at this
  *                                      many GB/s (0 = off, the default) -- timing only, results are unaffected
- *   DNAGPU_MULTI_OPT_PROBE_OWNER       rehearsal aid: only this owner (0 .. n-1) pulls and counts its buckets, the other
- *                                      ranks' histograms stay empty, so that on a shared device the call's times are one
- *                                      owner's own (-1 = off, the default: every owner counts) */
+ *   DNAGPU_MULTI_OPT_PROBE_OWNER       TIMING PROBE, RESULTS ARE PARTIAL: only this owner (0 .. n-1) pulls and counts its
+ *                                      buckets, the other ranks' histograms stay EMPTY (the sum of dnagpu_hist_total is then
+ *                                      smaller than `count`), so that on a shared device the call's times are one owner's
+ *                                      own (-1 = off, the default: every owner counts).  Never set it in a caller that uses
+ *                                      the groups.
+ *   DNAGPU_MULTI_OPT_EXCHANGE_RCCL     how dnagpu_count_multi_unordered moves the records between ranks: 0 (default) = every
+ *                                      owner pulls its buckets' pieces with peer copies; 1 = every piece is one ncclSend on its
+ *                                      rank's transfer stream and one ncclRecv on its owner's, one group call per bucket group
+ *                                      (needs dnagpu_multi_transport() == "rccl", else DNAGPU_ERR_BAD_ARG); 2 = as 1, and a
+ *                                      rank's own pieces go through RCCL too (so that one rank alone exercises the path) */
 #define DNAGPU_MULTI_OPT_PARTS             1
 #define DNAGPU_MULTI_OPT_EMULATE_LINK_GBS  2
 #define DNAGPU_MULTI_OPT_PROBE_OWNER       3
+#define DNAGPU_MULTI_OPT_EXCHANGE_RCCL     4
 #define DNAGPU_MULTI_MAX_PARTS             8
 #define DNAGPU_MULTI_DEFAULT_PARTS         3
 int dnagpu_multi_set_option(dnagpu_multi *m, int option, double value);
@@ -378,7 +398,7 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * work buffer before writing it sees garbage in every run, not only in a warm context. */
 #define DNAGPU_DEBUG_POISON_POOL 1u
 /* DNAGPU_DEBUG_FORCE_SUPERKMER: dnagpu_count_kmers_unordered takes the super-k-mer engine for every k it supports
- * (23..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
+ * (21..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
 #define DNAGPU_DEBUG_FORCE_SUPERKMER 2u
 /* DNAGPU_DEBUG_HEAVY_EXPAND: the super-k-mer engine expands its heavy mid buckets to keys for the ordinary levels (the
  * older path, still what records received from other ranks take when most of them are heavy) instead of splitting
@@ -415,6 +435,9 @@ typedef struct dnagpu_phase_times {
     float       ms[DNAGPU_MAX_PHASES];
 } dnagpu_phase_times;
 int dnagpu_last_phase_times(dnagpu_ctx *ctx, dnagpu_phase_times *out);
+/* The same for rank `rank` of the most recent dnagpu_count_multi_unordered on m: the phases of its record pass (level 0)
+ * followed by those of its owner phase (a name appears once per bucket group there). */
+int dnagpu_multi_last_phase_times(dnagpu_multi *m, int rank, dnagpu_phase_times *out);
 /* Enables (1) / disables (0) per-phase event timing; off by default (it adds event records only). */
 int dnagpu_set_profiling(dnagpu_ctx *ctx, int enabled);
 

@@ -29,7 +29,7 @@ def test_error_texts_are_the_references():
     assert pkg.strerror(1) == "Invalid k value: must be between 1 and 32"            # dna.c:773
     assert pkg.strerror(2) == "Qkmer pattern and kmer lengths do not match"          # dna.c:1107
     assert pkg.strerror(3) == "Prefix length cannot exceed kmer length"              # dna.c:855
-    assert pkg.abi_version() == 1
+    assert pkg.abi_version() == 2
 
 
 def test_kmer_count_rule():

@@ -615,7 +615,7 @@ def check_hist_unordered(hist, ok, oc, what):
     # not 0 are exactly the groups (an unordered histogram pads the range of a bucket that held copies)
     ext = hist.extent
     assert ext >= hist.distinct
-    if 0 < ext <= 50_000_000:
+    if 0 < ext <= 50_000_000 and hist.n_parts == 1:      # (a histogram of several parts has no arrays of its own)
         rk = hist.ctx.download_u64(hist.device_keys, ext)
         rc = hist.ctx.download_u64(hist.device_counts, (ext + 1) // 2).view(np.uint32)[:ext]
         keep = rc != 0
@@ -1102,6 +1102,18 @@ def test_pool_guard_bands_catch_a_write_past_the_end(pkg):
 
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
+def rank_device_maps(pkg, n_ranks):
+    """device lists for n_ranks ranks: all on device 0 (what a one-GPU test box can run), and -- on a box with two or
+    more devices -- the ranks spread over min(n_ranks, device_count) DISTINCT devices, so that the peer copies (and the
+    RCCL communicator) really cross a link."""
+    maps = [([0] * n_ranks, "shared")]
+    n_dev = pkg.device_count()
+    if n_dev >= 2 and n_ranks >= 2:
+        use = min(n_ranks, n_dev)
+        maps.append(([r % use for r in range(n_ranks)], f"{use} devices"))
+    return maps
+
+
 @pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
 def test_count_multi_one_process(pkg, n_ranks):
     """dnagpu_count_multi: N ranks driven from one process (every rank mapped to device 0 here, copy transport;
@@ -1109,21 +1121,24 @@ def test_count_multi_one_process(pkg, n_ranks):
     ranks' ascending downloads concatenated in rank order == the oracle's sorted histogram."""
     n, seed = 3_000_017, 0xD2A0003
     words = orc.synth_words(seed, n)
-    with pkg.Multi([0] * n_ranks, pkg.MULTI_COPY) as m:
-        assert m.transport == "copy"
-        for make in ("synth", "upload"):
-            d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
-            for k, first, count in ((31, 0, None), (21, 1000, 2_000_000), (8, 0, None), (3, 5, 1_000_000)):
-                ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False)[first:None if count is None else first + count])
-                hs = m.count(d, k, first, count)
-                gk = np.concatenate([h.download()[0] for h in hs])
-                gc = np.concatenate([h.download()[1] for h in hs])
-                assert sum(h.total for h in hs) == int(oc.sum())
-                assert_same(gk, ok, f"multi {n_ranks} ranks ({make}) k={k} keys")
-                assert_same(gc, oc, f"multi {n_ranks} ranks ({make}) k={k} counts")
-                for h in hs:
-                    h.free()
-            m.dna_free(d)
+    for devices, where in rank_device_maps(pkg, n_ranks):
+        distinct = len(set(devices)) == n_ranks and n_ranks > 1
+        # distinct devices: whatever DNAGPU_MULTI_AUTO gives (RCCL all-gather / reduce when the communicator can be made)
+        with pkg.Multi(devices, pkg.MULTI_AUTO if distinct else pkg.MULTI_COPY) as m:
+            assert m.transport in ("copy", "rccl") and (distinct or m.transport == "copy")
+            for make in ("synth", "upload"):
+                d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
+                for k, first, count in ((31, 0, None), (21, 1000, 2_000_000), (8, 0, None), (3, 5, 1_000_000)):
+                    ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False)[first:None if count is None else first + count])
+                    hs = m.count(d, k, first, count)
+                    gk = np.concatenate([h.download()[0] for h in hs])
+                    gc = np.concatenate([h.download()[1] for h in hs])
+                    assert sum(h.total for h in hs) == int(oc.sum())
+                    assert_same(gk, ok, f"multi {n_ranks} ranks on {where} ({make}) k={k} keys")
+                    assert_same(gc, oc, f"multi {n_ranks} ranks on {where} ({make}) k={k} counts")
+                    for h in hs:
+                        h.free()
+                m.dna_free(d)
 
 
 @pytest.mark.parametrize("n_ranks,parts", [(1, 1), (2, 2), (3, 3), (8, 2), (8, 1), (2, 8)])
@@ -1134,9 +1149,22 @@ def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
     histogram, whatever the number of bucket groups per owner; short k-mers take the ordered paths."""
     n, seed = 3_000_017, 0xD2A0003
     words = orc.synth_words(seed, n)
-    with pkg.Multi([0] * n_ranks, pkg.MULTI_COPY) as m:
+    runs = [(devices, where, 0) for devices, where in rank_device_maps(pkg, n_ranks)]
+    if len(runs) > 1 and len(set(runs[1][0])) == n_ranks:
+        runs.append((runs[1][0], runs[1][1] + ", RCCL send/recv", 1))      # the same exchange through ncclSend / ncclRecv
+    for devices, where, via_rccl in runs:
+        _count_multi_unordered_case(pkg, n_ranks, parts, devices, where, via_rccl, n, seed, words)
+
+
+def _count_multi_unordered_case(pkg, n_ranks, parts, devices, where, via_rccl, n, seed, words):
+    shared = len(set(devices)) < len(devices)
+    with pkg.Multi(devices, pkg.MULTI_COPY if shared else pkg.MULTI_AUTO) as m:
         m.set_parts(parts)
-        if parts == 2 and n_ranks == 2:
+        if via_rccl:
+            if m.transport != "rccl":
+                return                      # (no communicator on this box: the copy transport was the first run)
+            m.set_exchange_rccl(1)
+        if parts == 2 and n_ranks == 2 and shared:
             m.emulate_link(50.0)            # the rehearsal delay kernel on the transfer stream: timing only
         for make in ("synth", "upload"):
             d = m.synth(seed, n) if make == "synth" else m.upload(words, n)
@@ -1165,8 +1193,11 @@ def test_count_multi_unordered_one_process(pkg, n_ranks, parts):
                 if k >= 21:
                     lt = m.last_times()
                     assert lt["parts"] == parts and lt["total_ms"] > 0
+                    assert m.exchange_transport == ("rccl-sendrecv" if via_rccl else "peer-copy"), where
                     if count is None:           # (a window may lie in one rank's chunk: then nothing travels)
                         assert (lt["bytes_moved"] > 0) == (n_ranks > 1)
+                    names = [nm for nm, _ in m.rank_phase_times(0)]
+                    assert any(nm.startswith("sk_scatter0") for nm in names) and "sk_count" in names, names
                 for h in hs:
                     h.free()
             m.dna_free(d)
@@ -1183,12 +1214,43 @@ def test_bench_gpus2_one_process_rehearsal():
                           "--n-bases", "200000000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["launcher"] == "one-process" and line["unit"] == "k-mers/s"
+    pkg = load_package()
+    assert line["ranks"] == 2 and line["launcher"] == "one-process" and line["unit"] == "k-mers/s"
+    assert line["n_gpus"] == min(2, pkg.device_count())
     assert line["config"]["distinct"] > 0 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["roofline"] and line["exchange"]["parts"] >= 1
-    pkg = load_package()
+    # the line verifies itself: the ranks' digests summed; 200 Mbase is not a BASELINE config, so only sum(count) == rows
+    assert line["digest_total_ok"] is True and line["digest_ok"] is None and line["digest"]["total"] == 200000000 - 31 + 1
+    assert any(nm.startswith("sk_scatter0") for nm in line["phases_ms"]) and "sk_count" in line["phases_ms"]
     if pkg.device_count() < 2:
-        assert line["rehearsal"] is True and line["transport"] == "copy" and line["devices"] == [0, 0]
+        assert line["rehearsal"] is True and line["exchange_transport"] == "peer-copy" and line["rccl_ranks"] == 0
+        assert line["devices"] == [0, 0]
+
+
+def test_bench_digest_check_flips_on_a_wrong_digest(tmp_path):
+    """bench.py's self-check: config 3 (k = 31, 248,956,422 bases) prints digest_ok true against the oracle's digest and
+    exits 0; the same run against a copy of the golden file with one value changed prints digest_ok false and exits 3."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from __graft_entry__ import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["digest_ok"] is True and line["digest_total_ok"] is True
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))["3"]
+    assert line["digest"] == {f: want[f] for f in ("total", "distinct", "unique", "checksum")}
+    # a wrong expectation (the checker must be able to fail): BENCH_DIGESTS points bench.py at a doctored copy
+    bad = json.load(open(os.path.join(ROOT, "tests", "golden", "config_digests.json")))
+    bad["3"]["checksum"] ^= 1
+    p = tmp_path / "digests.json"
+    p.write_text(json.dumps(bad))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, BENCH_DIGESTS=str(p)))
+    assert out.returncode == 3
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["digest_ok"] is False and line["digest_expected"]["checksum"] == bad["3"]["checksum"]
 
 
 def test_count_multi_rccl_one_rank(pkg, ctx):
@@ -1210,6 +1272,34 @@ def test_count_multi_rccl_one_rank(pkg, ctx):
         m.dna_free(d)
     with pytest.raises(pkg.DnaGpuError):
         pkg.Multi([0, 0], pkg.MULTI_RCCL)          # RCCL needs distinct devices
+
+
+def test_count_multi_unordered_rccl_sendrecv_one_rank(pkg, ctx):
+    """The record exchange through RCCL (DNAGPU_MULTI_OPT_EXCHANGE_RCCL) with the one device a test box has: mode 2 sends
+    a rank's OWN pieces through ncclSend / ncclRecv too, so one rank alone runs the group calls, the piece offsets and the
+    landing layout; the groups are the oracle's.  Without a communicator the option is refused."""
+    ctx.trim()
+    n, seed = 3_000_017, 0xD2A0003
+    words = orc.synth_words(seed, n)
+    with pkg.Multi([0], pkg.MULTI_COPY) as m:
+        with pytest.raises(pkg.DnaGpuError):
+            m.set_exchange_rccl(1)
+    with pkg.Multi([0], pkg.MULTI_RCCL) as m:
+        m.set_exchange_rccl(2)
+        d = m.synth(seed, n)
+        for parts in (1, 3):
+            m.set_parts(parts)
+            for k in (31, 21):
+                hs = m.count_unordered(d, k)
+                assert m.exchange_transport == "rccl-sendrecv" and m.rccl_ranks == 1
+                ok, oc = orc.count_kmers(words, n, k)
+                check_hist_unordered(hs[0], ok, oc, f"rccl send/recv, one rank, {parts} parts, k={k}")
+                hs[0].free()
+        m.set_exchange_rccl(0)
+        hs = m.count_unordered(d, 31)
+        assert m.exchange_transport == "peer-copy"
+        hs[0].free()
+        m.dna_free(d)
 
 
 # ------------------------------------------------------------------ BASELINE.json sizes (properties)
