@@ -118,6 +118,7 @@ def lib():
     L.dnagpu_count_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_count_kmers_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_hist_is_sorted.argtypes = [vp]
+    L.dnagpu_count_kmers_batch.argtypes = [vp, vp, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]
     L.dnagpu_sk_buckets.argtypes = [vp, C.c_uint64, C.c_int]
     L.dnagpu_sk_records.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_records_buckets.argtypes = [vp]
@@ -513,6 +514,14 @@ class Context:
             count = max(total - first, 0)
         h = C.c_void_p()
         _chk(lib().dnagpu_count_kmers_unordered(self.h, dna.h, k, first, count, C.byref(h)))
+        return Hist(self, h)
+
+    def count_kmers_batch(self, dna, seq_starts, k):
+        """GROUP BY over a table of sequences (test.sql:140-150): dna = the sequences back to back, seq_starts = the first
+        base of each + the total (n_seqs + 1 entries)"""
+        st = np.ascontiguousarray(seq_starts, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_kmers_batch(self.h, dna.h, st.ctypes.data_as(u64p), max(len(st) - 1, 0), k, C.byref(h)))
         return Hist(self, h)
 
     # ---- the unordered count in two halves (rows on several GPUs: sharded.count_sharded_exchange_records)

@@ -127,6 +127,10 @@ struct dnagpu_ctx {
     u64 *mailbox;
     u64 mailbox_seq = 0;      // sequence number of the last flagged read-back (read_back)
     unsigned debug_flags;     // DNAGPU_DEBUG_*
+    // a count over a TABLE of sequences (dnagpu_count_kmers_batch): one bit per base of the packed stream, set where a
+    // sequence starts; null otherwise.  Level 0 of the super-k-mer engine makes no record of rows that reach across a mark.
+    const u32 *batch_marks = nullptr;
+    u64 batch_mark_words = 0;
 };
 constexpr size_t MAILBOX_BYTES = (size_t)1 << 20;
 
@@ -1470,7 +1474,7 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     RC_TRY(sk_level_begin(ctx, ps, cur, 1, r0bits, (u32)chunk_rows, &l0));
     prof_mark(ctx, "sk_hist0");
     HIP_TRY(launch_sk_level0(false, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
-                             l0.hist, nullptr, nullptr, st));
+                             l0.hist, nullptr, nullptr, st, nullptr, ctx->batch_marks, ctx->batch_mark_words));
     prof_mark(ctx, "sk_prefix0");
     HIP_TRY(launch_level_prefix(cur, l0.chunks, l0.n_chunks, 1, (u32)chunk_rows, l0.hist, l0.tot, st));
     HIP_TRY(launch_level_children(cur, 1, l0.tot, l0.next, nullptr, nullptr, nullptr, 0, st));
@@ -1496,7 +1500,7 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     ps.ptrs.push_back(rec0);
     prof_mark(ctx, "sk_scatter0");
     HIP_TRY(launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, c0n, (u32)b1, (u32)r0bits,
-                             l0.hist, l0.tot, rec0, st));
+                             l0.hist, l0.tot, rec0, st, nullptr, ctx->batch_marks, ctx->batch_mark_words));
     *rec0_out = rec0;
     *coarse = l0.next;
     *n_coarse = l0.n_next;
@@ -1554,7 +1558,7 @@ static int sk_level0_slab(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna,
     HIP_TRY(hipMemsetAsync(est, 0, (size_t)sk_max_c0() * sizeof(u32), st));
     HIP_TRY(launch_sk_sample_chunks(samp, n_samp, (u32)samp_stride, (u32)samp_len, (u32)n, st));
     HIP_TRY(launch_sk_level0(false, samp, n_samp, dna->words, dna->n_words, first, k, g.c0n, (u32)g.b1, (u32)g.r0bits, nullptr, nullptr,
-                             nullptr, st, est));
+                             nullptr, st, est, ctx->batch_marks, ctx->batch_mark_words));
     HIP_TRY(launch_sk_slab_init(est, (u32)g.r0bits, (u32)chunk_rows, (u32)sampled, l0.n_chunks, slab, nodes, st));
     std::vector<u32> h_est(r0n);
     RC_TRY(read_back(ctx, h_est.data(), est, (size_t)r0n * sizeof(u32)));
@@ -1579,7 +1583,7 @@ static int sk_level0_slab(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna,
     RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(cap, 1) * 16, &rec0));
     prof_mark(ctx, "sk_scatter0");
     const hipError_t e = launch_sk_level0(true, l0.chunks, l0.n_chunks, dna->words, dna->n_words, first, k, g.c0n, (u32)g.b1,
-                                          (u32)g.r0bits, nullptr, nullptr, rec0, st, slab);
+                                          (u32)g.r0bits, nullptr, nullptr, rec0, st, slab, ctx->batch_marks, ctx->batch_mark_words);
     u32 status[2] = {1, 0};
     int rc = e == hipSuccess ? read_back(ctx, status, slab + 18 * (size_t)sk_max_c0(), sizeof status) : DNAGPU_ERR_HIP;
     if (rc != DNAGPU_OK || status[0] || status[1] != (u32)span || (ctx->debug_flags & DNAGPU_DEBUG_SLAB0_OVERFLOW)) {
@@ -1797,10 +1801,11 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
 static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, u32 n_fin, const SkHeavy &heavy, u64 n, int k,
                          dnagpu_hist *h);
 
-static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, dnagpu_hist *h)
+// n = rows swept; n_kmers_expected = the k-mers they hold (fewer over a table of sequences: ctx->batch_marks)
+static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, dnagpu_hist *h, u64 n_kmers_expected)
 {
     PoolScope ps(ctx);
-    const SkGeom g = sk_geometry(ctx, n, k);
+    const SkGeom g = sk_geometry(ctx, std::max<u64>(n_kmers_expected, 1), k);
     void *rec0 = nullptr, *recs = nullptr;
     Node *coarse = nullptr, *fin = nullptr;
     u32 n_coarse = 0, n_fin = 0;
@@ -1819,9 +1824,9 @@ static int count_sk(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, in
         for (size_t i = 0; i < kids.size(); i++)
             lens[i] = kids[i].len;
     }
-    RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n, &recs, &fin, &n_fin, &heavy, &n_kmers,
+    RC_TRY(sk_levels12(ctx, ps, g, coarse, n_coarse, rec0, n_recs, n_kmers_expected, &recs, &fin, &n_fin, &heavy, &n_kmers,
                        lens.size() == n_coarse ? lens.data() : nullptr, rec0_cap));
-    return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n, k, h);
+    return count_sk_tail(ctx, ps, recs, fin, n_fin, heavy, n_kmers_expected, k, h);
 }
 
 // Records that arrive from elsewhere (the multi-GPU exchange: every rank cuts the records of its own chunk and ships each
@@ -2177,7 +2182,7 @@ static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, 
     int rc;
     const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && n >= 64;
     if (any_order && dna && fixed_bits == 0 && n_owners == 1 && (sk_is_default(n, k) || force_sk)) {
-        rc = count_sk(ctx, dna, first, n, k, h);
+        rc = count_sk(ctx, dna, first, n, k, h, n);
         if (rc != DNAGPU_SK_SKEWED) {
             prof_end(ctx);
             if (rc != DNAGPU_OK) {
@@ -2348,6 +2353,86 @@ extern "C" int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *d
     RC_TRY(check_range(dna, k, first, count));
     HIP_TRY(hipSetDevice(ctx->device));
     return count_core(ctx, dna, first, count, k, nullptr, out, 0, 0, 0, 1, true);
+    });
+}
+
+// ---- GROUP BY kmer, count(*) FROM a table of sequences, LATERAL generate_kmers(sequence, k) (test.sql:140-150)
+extern "C" int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs,
+                                        int k, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || !out || (n_seqs && !seq_starts))
+        return DNAGPU_ERR_BAD_ARG;
+    if (k < 1 || k > 32)
+        return DNAGPU_ERR_INVALID_K;               // dna.c:771-773, raised by the first row's generate_kmers call
+    *out = nullptr;
+    // the rows of the table: every sequence's own generate_kmers rows (none for a sequence shorter than k)
+    u64 rows = 0;
+    for (u64 i = 0; i < n_seqs; i++) {
+        if (seq_starts[i + 1] < seq_starts[i])
+            return DNAGPU_ERR_BAD_ARG;
+        const u64 len = seq_starts[i + 1] - seq_starts[i];
+        if (len >= (u64)k)
+            rows += len - (u64)k + 1;
+    }
+    if (n_seqs && (seq_starts[0] != 0 || seq_starts[n_seqs] != dna->n_bases))
+        return DNAGPU_ERR_BAD_ARG;
+    if (n_seqs == 0 && dna->n_bases != 0)
+        return DNAGPU_ERR_BAD_ARG;
+    if (rows > 0xFFFFFFFFull || dna->n_bases > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (rows == 0)
+        return count_core(ctx, nullptr, 0, 0, k, nullptr, out);
+    if (n_seqs == 1)                               // one sequence: the plain count
+        return count_core(ctx, dna, 0, rows, k, nullptr, out, 0, 0, 0, 1, true);
+    PoolScope ps(ctx);
+    hipStream_t st = ctx->stream;
+    // ---- the marks: one bit per base, set where a sequence starts
+    const u64 n_mark_words = dna->n_bases / 32 + 3;
+    u32 *marks = nullptr;
+    u64 *d_starts = nullptr;
+    RC_TRY(ps.alloc((size_t)n_mark_words, &marks));
+    RC_TRY(ps.alloc((size_t)n_seqs + 1, &d_starts));
+    HIP_TRY(hipMemcpyAsync(d_starts, seq_starts, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_batch_marks(d_starts, n_seqs, marks, n_mark_words, st));
+    HIP_TRY(hipStreamSynchronize(st));             // (seq_starts is the caller's: not kept behind the call)
+    const u64 n_windows = dna->n_bases - (u64)k + 1;   // (rows > 0: some sequence has k bases)
+    // ---- long k-mers of long tables: the super-k-mer engine, its level 0 blind to the rows across sequence starts
+    const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && rows >= 64;
+    if (sk_is_default(rows, k) || force_sk) {
+        dnagpu_hist *h = new (std::nothrow) dnagpu_hist{nullptr, nullptr, 0, rows, nullptr, nullptr, nullptr, 0, true};
+        if (!h)
+            return DNAGPU_ERR_OOM;
+        prof_begin(ctx);
+        ctx->batch_marks = marks;
+        ctx->batch_mark_words = n_mark_words;
+        const int rc = count_sk(ctx, dna, 0, n_windows, k, h, rows);
+        ctx->batch_marks = nullptr;
+        ctx->batch_mark_words = 0;
+        prof_end(ctx);
+        if (rc == DNAGPU_OK) {
+            *out = h;
+            return DNAGPU_OK;
+        }
+        delete h;
+        if (rc != DNAGPU_SK_SKEWED)
+            return rc;                             // (else: the keys below)
+    }
+    // ---- every other case: the keys of the table's rows, compacted, then the ordinary count over keys
+    u64 *keys = nullptr;
+    unsigned long long *cursor = nullptr;
+    RC_TRY(ps.alloc((size_t)rows, &keys));
+    RC_TRY(ps.alloc(1, &cursor));
+    HIP_TRY(launch_batch_keys(dna->words, dna->n_words, marks, n_mark_words, n_windows, k, keys,
+                              cursor, st));
+    u64 got = 0;
+    RC_TRY(read_back(ctx, &got, cursor, 8));
+    if (got != rows) {
+        set_err("table count: %llu rows kept, %llu expected", (unsigned long long)got, (unsigned long long)rows);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    return count_core(ctx, nullptr, 0, rows, k, keys, out);
     });
 }
 

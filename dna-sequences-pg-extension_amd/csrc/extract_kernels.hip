@@ -107,6 +107,91 @@ __global__ __launch_bounds__(256) void hash_batch_kernel(const u64 *__restrict__
         __builtin_nontemporal_store(pg_kmer_hash(__builtin_nontemporal_load(&keys[i])), &out[i]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A table of sequences in one packed stream (GROUP BY over FROM table, LATERAL generate_kmers(sequence, k):
+// test.sql:140-150).  marks: one bit per base, set where a sequence starts.
+__global__ __launch_bounds__(256) void batch_marks_kernel(const u64 *__restrict__ starts, u64 n_seqs, u32 *__restrict__ marks,
+                                                          u64 n_mark_words)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;      // starts[0] = 0 marks nothing
+    if (i >= n_seqs)
+        return;
+    const u64 b = starts[i];
+    if ((b >> 5) < n_mark_words)
+        atomicOr(&marks[b >> 5], 1u << (b & 31));
+}
+
+hipError_t launch_batch_marks(const u64 *starts, u64 n_seqs, u32 *marks, u64 n_mark_words, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(marks, 0, (size_t)n_mark_words * sizeof(u32), s);
+    if (e != hipSuccess || n_seqs < 2)
+        return e;
+    hipLaunchKernelGGL(batch_marks_kernel, dim3((unsigned)((n_seqs - 1 + 255) / 256)), dim3(256), 0, s, starts, n_seqs, marks,
+                       n_mark_words);
+    return hipGetLastError();
+}
+
+// The keys of the table's rows for the engines that take keys (short k-mers, short tables): a wave owns 1024 consecutive
+// rows, 16 rounds of one row per lane; a row is kept when no sequence starts among the k - 1 bases behind its first (its
+// window lies in one sequence).  The wave's kept keys wait in registers, one returning add reserves their slots, and every
+// round's keys go out as one contiguous run.  Order of the keys: none (they are counted).
+constexpr int BK_ROUNDS = 16;
+__global__ __launch_bounds__(256) void batch_keys_kernel(const u64 *__restrict__ words, u64 n_words, const u32 *__restrict__ marks,
+                                                         u64 n_mark_words, u64 n_rows, int k, u64 *__restrict__ out_keys,
+                                                         unsigned long long *__restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63;
+    const u64 wave = (u64)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const u64 row0 = wave * (u64)(64 * BK_ROUNDS);
+    if (row0 >= n_rows)
+        return;
+    const u64 kmask = kmer_mask(k);
+    const u32 span = (u32)k - 1u;                                      // marks at bases p + 1 .. p + k - 1 spoil row p
+    u64 key[BK_ROUNDS];
+    u32 keep = 0, before[BK_ROUNDS], total = 0;
+#pragma unroll
+    for (int r = 0; r < BK_ROUNDS; r++) {
+        const u64 p = row0 + (u64)r * 64 + lane;
+        bool ok = p < n_rows;
+        key[r] = 0;
+        if (ok) {
+            key[r] = key_at(words, n_words, p, kmask);
+            if (span) {
+                const u64 q = p + 1, mw = q >> 5;
+                const unsigned sh = (unsigned)(q & 31);
+                const u64 m0 = mw < n_mark_words ? marks[mw] : 0u, m1 = mw + 1 < n_mark_words ? marks[mw + 1] : 0u;
+                const u32 bits = (u32)(((m1 << 32) | m0) >> sh);       // marks of bases q .. q + 31
+                ok = (bits & (span >= 32u ? ~0u : (1u << span) - 1u)) == 0;
+            }
+        }
+        const u64 b = __ballot(ok);
+        before[r] = total + (u32)__popcll(b & (((u64)1 << lane) - 1));
+        total += (u32)__popcll(b);
+        keep |= ok ? 1u << r : 0u;
+    }
+    unsigned long long base = 0;
+    if (lane == 0 && total)
+        base = atomicAdd(cursor, (unsigned long long)total);
+    base = ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (u32)__builtin_amdgcn_readfirstlane((int)(u32)base);
+#pragma unroll
+    for (int r = 0; r < BK_ROUNDS; r++)
+        if ((keep >> r) & 1u)
+            __builtin_nontemporal_store(key[r], &out_keys[base + before[r]]);
+}
+
+hipError_t launch_batch_keys(const u64 *words, u64 n_words, const u32 *marks, u64 n_mark_words, u64 n_rows, int k, u64 *out_keys,
+                             unsigned long long *cursor, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || n_rows == 0)
+        return e;
+    const u64 per_block = (u64)4 * 64 * BK_ROUNDS;
+    hipLaunchKernelGGL(batch_keys_kernel, dim3((unsigned)((n_rows + per_block - 1) / per_block)), dim3(256), 0, s, words, n_words, marks,
+                       n_mark_words, n_rows, k, out_keys, cursor);
+    return hipGetLastError();
+}
+
 hipError_t launch_hash_batch(const u64 *keys, u64 n, u32 *out, hipStream_t s)
 {
     if (n == 0)

@@ -158,6 +158,14 @@ hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u3
                                 u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,
                                 u64 *dst_counts, hipStream_t s);
 
+// ---- a table of sequences in one packed stream (extract_kernels.hip)
+// marks: bit b set where a sequence starts at base b (starts[1 .. n_seqs - 1]; the buffer is zeroed here)
+hipError_t launch_batch_marks(const u64 *starts, u64 n_seqs, u32 *marks, u64 n_mark_words, hipStream_t s);
+// the keys of the rows of the table -- windows [p, p + k) of rows [0, n_rows) that reach across no mark -- in no
+// particular order; *cursor (zeroed here) ends as their number
+hipError_t launch_batch_keys(const u64 *words, u64 n_words, const u32 *marks, u64 n_mark_words, u64 n_rows, int k, u64 *out_keys,
+                             unsigned long long *cursor, hipStream_t s);
+
 // ---------------------------------------------------------------- superkmer_kernels.hip
 // super-k-mer (minimizer) partitioning for long k-mers: the dna sweeps (level 0: records per coarse digit of every
 // chunk of rows / records scattered into the coarse buckets), the record level (level 1: d1), and the expansion of
@@ -172,9 +180,11 @@ int sk_max_c0();          // most coarse buckets the level-0 sweeps support
 // the histogram sweep -- every chunk reserves sk_slab_cap(est ...) slots of every digit's region, unused slots become NULL
 // records (bit 63 of the second word; level 1 skips them), aux[17 * sk_max_c0() + d] = records stored per digit,
 // aux[18 * sk_max_c0()] = 1 if a chunk ran out of slots, aux[18 * sk_max_c0() + 1] = slots of all regions.
+// marks (or null): one bit per base of the packed stream, set where a sequence of a TABLE of sequences starts
+// (dnagpu_count_kmers_batch): rows whose k-mer reaches across a start are rows of no sequence and make no record.
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
                             u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s,
-                            u32 *aux = nullptr);
+                            u32 *aux = nullptr, const u32 *marks = nullptr, u64 n_mark_words = 0);
 hipError_t launch_sk_sample_chunks(Chunk *chunks, u32 n_chunks, u32 stride, u32 len, u32 n, hipStream_t s);
 int sk_slab_words();
 u32 sk_slab_cap(u32 est, u64 chunk_rows, u64 sampled);

@@ -7,7 +7,11 @@
 //              of the k-mer's content alone, so equal k-mers share it wherever they occur
 //   bucket     = three digits (d0 < C0, d1 < 2^b1, d2 < 16) cut from a multiplicative re-mix of that hash
 //   record     = a run of consecutive k-mers with the same minimizer hash (on random data 9 k-mers on
-//              average, never more than SK_LMAX): 16 bytes = up to 54 bases (108 bits) + length + d1 + d2
+//              average, never more than SK_LMAX): 16 bytes = up to 54 bases (108 bits) + length + d1 + d2.
+//              A record cut from a PLAIN tile (all of random sequence) is a run of k-mers whose leftmost minimum m-mer is
+//              the SAME OCCURRENCE (same hash, same position): at most w k-mers, at most 2k - m bases, and the record
+//              carries that m-mer's offset (SK_POS_*); every other record (low-complexity stretches, the partial tiles at
+//              a sequence's end) has SK_REC_MULTI set.  sk_count tests records instead of k-mers with this (see there).
 //
 //   sk_hist0 / sk_scatter0   sweep the packed dna: hashes, window minima, runs -> records scattered
 //                            into C0 coarse buckets (1.8 B per k-mer instead of 8).  Long sequences: the scatter sweep
@@ -29,6 +33,7 @@
 // test.sql:95-104).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -46,6 +51,15 @@ int sk_count_cap() { return 4096; }              // distinct keys of a bucket <=
 
 typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
 
+// Second word of a record: bases 32..53 (bits 0..43) | (len - 1) << 44 | d1 << 49 | d2 << 59 | bit 63: NULL record.
+// Bit 58 (SK_REC_MULTI): the record's k-mers do NOT all have their leftmost minimum m-mer at one place (nothing is known
+// about where it is).  Clear: they do, and bits 39..43 (free: such a record has at most 2k - m <= 49 bases, i.e. payload
+// bits 0..97 = bits 0..33 of this word) hold that m-mer's offset from the record's first base, 0 .. w - 1 <= 17.
+constexpr int SK_REC_MULTI_BIT = 58;
+constexpr int SK_POS_SHIFT = 39;                 // (k-mers of the record never reach these bits: consumers mask keys with kmask)
+constexpr u32 SK_POS_MASK = 31u;
+constexpr u32 SK_GPOS_MASK = 63u;                // low bits of a window minimum: the position of the minimum (see sk_front)
+
 // bijective 32-bit mix of the 30-bit m-mer value: distinct m-mers never tie.  Four operations (the sweeps of level 0 are
 // bound by VALU instruction issue: 36 per row in round 2, 9 of them this hash): on random sequence the order it gives
 // makes runs as long as the seven-operation mix it replaces (8.99 k-mers per record at k = 31; tools/hash_eval.py).
@@ -58,13 +72,15 @@ __device__ __forceinline__ u32 sk_mix(u32 h)
 }
 
 // the three bucket digits of a minimizer hash.  The minimum of w hashes is small, i.e. its high bits are biased: the
-// digits are cut from a product of the hash's LOW 24 bits (unbiased) with an odd constant -- v_mul_u32_u24 is a
+// digits are cut from a product of 24 LOW bits of the hash (unbiased) with an odd constant -- v_mul_u32_u24 is a
 // full-rate instruction, the 32-bit multiply this replaces a quarter-rate one.  d2 and d1 come from product bits 2..15
 // (functions of the hash's low 16 bits), d0 from bits 16..31 scaled to [0, c0) by a second 24-bit multiply.
 struct SkDigits {
     u32 d0, d1, d2;
 };
-__device__ __forceinline__ u32 sk_digit_word(u32 hmin) { return __umul24(hmin, 0x9E3779u); }
+// (hmin = a window minimum as sk_front makes it: hash bits 7..31, bit 6 set, the minimum's position in bits 0..5 -- the
+// digits are cut from hash bits 7..30)
+__device__ __forceinline__ u32 sk_digit_word(u32 hmin) { return __umul24(hmin >> 7, 0x9E3779u); }
 __device__ __forceinline__ u32 sk_digit0(u32 g, u32 c0) { return __umul24(g >> 16, c0) >> 16; }
 __device__ __forceinline__ SkDigits sk_digits(u32 hmin, u32 c0, u32 b1mask)
 {
@@ -114,13 +130,24 @@ __device__ __forceinline__ u32 wave_prev(u32 x) { return (u32)__builtin_amdgcn_u
 // lane 62's windows).  What a lane needs of its neighbours -- the next lane's first W-1 hashes, the boundary minima, the
 // last run break before its rows -- moves by DPP wave shifts and a DPP scan: no LDS, no barrier (round 2's workgroup
 // tile exchanged them through LDS behind five workgroup barriers; the two sweeps together took 7.9 ms at 3 Gbase).
-// Every lane ends with the window-minimum hash of each of its rows in hm[]; sk_front_open adds the state of the record
+// Every lane ends with the window minimum of each of its rows in hm[]; sk_front_open adds the state of the record
 // that is open at its first row.  Records are cut at tile boundaries (one extra record per 2016 rows: +0.4 %).
+//   A minimum is hash bits 7..31 | 64 | position: the m-mers' hashes carry, in their low six bits, their own position
+//   relative to the lane's first row (0 .. 31 + W - 1), so the minimum of a window is its smallest 25-bit hash and, among
+//   equal ones, the LEFTMOST -- a function of the k-mer's content, like the hash.  Two neighbouring rows with equal hm
+//   have the same m-mer occurrence as their minimum.  (Distinct m-mers may now tie on the 25 bits: 2^-25 per pair; the
+//   bucket digits use the hash part only, so equal k-mers still share their bucket.)  Bit 6 is set in every real hash, so
+//   that 0 is smaller than all of them:
+//   BATCH (a table of sequences in one packed stream, dnagpu_count_kmers_batch: `marks` = one bit per base, set where a
+//   sequence starts): an m-mer that reaches across a sequence start hashes to 0.  A k-mer's window holds such an m-mer
+//   exactly when the k-mer itself reaches across a start, so the rows that are NOT rows of the table -- and only they --
+//   have the minimum 0; they form runs of their own, which are counted and stored nowhere.
 template <int W>
 struct SkFront {
     u32 hm[32];
-    u32 next_first;        // hm[0] of the next lane (lane 63: 0)
-    u32 prev_last;         // hm[31] of the lane before (lane 0: 0)
+    u32 next_first;        // hm[0] of the next lane, its position in THIS lane's terms (+ 32)
+    u32 prev_last;         // hm[31] of the lane before, its position in this lane's terms (- 32: a position before this lane's
+                           // first row borrows from the hash part -- it then equals no minimum of this lane, rightly)
     u32 n_valid;           // rows of this lane that exist (0..32)
     u32 n_rows;            // rows of the tile
     bool plain;            // wave-uniform: a full tile whose records are its natural runs (see sk_front)
@@ -129,10 +156,11 @@ struct SkFront {
     u32 c0;                // length so far of the record open at this lane's first row
 };
 
-template <int W>
+template <int W, bool BATCH = false>
 __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 n_rows,
                                          u32 lmax, u32 mmask /* 2 m ones: the m-mer */,
-                                         u64 *wsh /* this wave's [66] or null: the tile's words, word 0 = the one holding pos0 */)
+                                         u64 *wsh /* this wave's [66] or null: the tile's words, word 0 = the one holding pos0 */,
+                                         const u32 *__restrict__ marks = nullptr, u64 n_mark_words = 0)
 {
     const int lane = threadIdx.x & 63;
     // the 64 bases from this lane's first row on (pos0 + 32 lane): 4 dwords
@@ -161,16 +189,35 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     constexpr int N = 32 + B;
     static_assert(W >= 9 && W <= 18, "window lengths of k = 23 .. 32 at m = 15");
     u32 a[N];
+    // BATCH: bit j of `within` = this lane's m-mer j reaches across no sequence start (no mark among the m - 1 bases behind
+    // its first): the marks of the 64 bases from the lane's first on, smeared over m - 1 places
+    u32 within = ~0u;
+    if (BATCH) {
+        const u64 mw = pos >> 5;
+        const unsigned msh = (unsigned)(pos & 31);                                 // wave-uniform
+        const u32 b0 = mw < n_mark_words ? marks[mw] : 0u, b1 = mw + 1 < n_mark_words ? marks[mw + 1] : 0u,
+                  b2 = mw + 2 < n_mark_words ? marks[mw + 2] : 0u;
+        const u64 S = ((u64)__builtin_amdgcn_alignbit(b2, b1, msh) << 32) | __builtin_amdgcn_alignbit(b1, b0, msh);
+        u64 r = S >> 1;                            // bit i: a sequence starts at base i + 1 of the lane's
+        r |= r >> 1;
+        r |= r >> 2;
+        r |= r >> 4;                               // ... starts among bases i + 1 .. i + 8
+        const unsigned mm1 = (unsigned)__popc(mmask) / 2u - 1u;                    // m - 1 (12 or 14)
+        r |= r >> (mm1 - 8u);                      // ... among bases i + 1 .. i + m - 1
+        within = ~(u32)r;
+    }
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const int q = (2 * j) >> 5, s = (2 * j) & 31;
         const u32 v = __builtin_amdgcn_alignbit(d[q + 1], d[q], s) & mmask;        // m bases
-        a[j] = sk_mix(v);
+        a[j] = (sk_mix(v) & ~SK_GPOS_MASK) | (64u | (u32)j);                       // (one v_and_or)
+        if (BATCH)
+            a[j] &= (u32)((int)(within << (31 - j)) >> 31);                        // (v_bfe_i32 + v_and)
     }
-    // the next lane's first W-1 hashes complete this lane's windows
+    // the next lane's first W-1 hashes complete this lane's windows (their positions: 32 ... in this lane's terms)
 #pragma unroll
     for (int j = 0; j < B; j++)
-        a[32 + j] = wave_next(a[j]);
+        a[32 + j] = wave_next(a[j]) + 32u;
     // Window minima in three operations per row whatever W (van Herk / Gil-Werman): cut a[] into blocks of B; with
     // suf[i] = min of a[i .. end of i's block] and pre[i] = min of a[start of i's block .. i], the window [i, i + B]
     // is suf[i] and pre[i + B] together (i + B sits in the next block at i's offset).  (Round 2 took the minima by
@@ -190,26 +237,29 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     f.n_valid = r0 >= n_rows ? 0u : (n_rows - r0 < 32u ? n_rows - r0 : 32u);
     f.n_rows = n_rows;
     // neighbours' boundary minima
-    f.next_first = wave_next(f.hm[0]);
-    f.prev_last = wave_prev(f.hm[31]);
-    // A PLAIN tile: full, and no run of equal minima longer than a record holds, so that its records are exactly its
-    // natural runs (cut at the tile's end).  On random sequence a run is at most W <= 18 rows (an m-mer occurrence stays
-    // the minimum of at most W windows); longer runs need a repeated m-mer (low-complexity sequence).  Test on every
-    // fourth row of the tile: six such samples in a row span 21 rows -- more than any run of W rows covers, and any run
-    // of more than lmax >= 23 rows covers six of them -- so six equal samples in a row send the tile through the
-    // general walk, and nothing else does.
+    f.next_first = wave_next(f.hm[0]) + 32u;
+    f.prev_last = wave_prev(f.hm[31]) - 32u;
+    // A PLAIN tile: full, and no run of equal minimum HASHES longer than 20 rows.  Its records are the runs of equal
+    // minima, hash AND position (cut at the tile's end): one m-mer occurrence stays the minimum of at most W <= 18
+    // windows, so such a record never outgrows lmax, and all its k-mers have their leftmost minimum m-mer at one place.
+    // On random sequence every tile is plain.  Longer runs of one hash need a repeated m-mer (low-complexity sequence):
+    // there the position moves on row after row, and the tile goes through the general walk, which cuts by hash alone
+    // every lmax rows (SK_REC_MULTI records).  Test on every fourth row of the tile: six such samples in a row span 21
+    // rows -- more than any run of W rows covers -- so six equal samples in a row send the tile through the general
+    // walk, and nothing else does.  (Shorter stretches of a repeated m-mer stay in plain tiles as a few short records.)
     u32 smp[13];
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        smp[i] = f.hm[4 * i];
+        smp[i] = f.hm[4 * i] >> 6;
 #pragma unroll
     for (int i = 0; i < 5; i++)
-        smp[8 + i] = i == 0 ? f.next_first : wave_next(f.hm[4 * i]);
+        smp[8 + i] = (i == 0 ? f.next_first : wave_next(f.hm[4 * i])) >> 6;
     bool long_run = false;
 #pragma unroll
     for (int i = 0; i < 8; i++)
         long_run = long_run || (smp[i] == smp[i + 1] && smp[i + 1] == smp[i + 2] && smp[i + 2] == smp[i + 3] &&
-                                smp[i + 3] == smp[i + 4] && smp[i + 4] == smp[i + 5]);
+                                smp[i + 3] == smp[i + 4] && smp[i + 4] == smp[i + 5] &&
+                                (!BATCH || smp[i] != 0u));   // (the k - 1 rows across a sequence start are no repeat)
     f.plain = n_rows == (u32)SKW_ROWS && __ballot(long_run && lane < 63) == 0;
 }
 
@@ -217,7 +267,15 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
 // before this one: the last natural break (a row whose minimum differs from the row before; the tile's first row counts)
 // among the lanes' rows -> ns0 = the start row of the natural run that reaches this lane's first row from the left, and
 // c0 = the length so far of the RECORD open there (records are cut every lmax rows of a run)
-template <int W>
+// two minima belong to different runs: by hash alone (BYG: the general walk of a non-plain tile), or by hash and position
+// (a plain tile whose list overflowed: the same records as its branch-free walk)
+template <bool BYG>
+__device__ __forceinline__ bool sk_differ(u32 x, u32 y)
+{
+    return BYG ? (x ^ y) > SK_GPOS_MASK : x != y;
+}
+
+template <bool BYG, int W>
 __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
 {
     const int lane = threadIdx.x & 63;
@@ -229,14 +287,16 @@ __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
     u32 lb = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
-        const bool brk = j == 0 ? (lane == 0 || f.hm[0] != f.prev_last) : (f.hm[j] != f.hm[j - 1]);
+        // (BYG compares hashes: prev_last + 32 is the lane before's minimum as it stood)
+        const bool brk = j == 0 ? (lane == 0 || sk_differ<BYG>(f.hm[0], BYG ? f.prev_last + 32u : f.prev_last))
+                                : sk_differ<BYG>(f.hm[j], f.hm[j - 1]);
         if (brk)
             lb = r0 + (u32)j + 1u;
     }
     const u32 before = wave_prev(wave_incl_max(lb));       // over the lanes before this one (lane 0: 0)
     // `before` >= 1 for every lane but lane 0 (row 0 is a break); lane 0's own row 0 is a break too
     f.ns0 = before ? before - 1u : 0u;
-    const bool first_break = lane == 0 || f.hm[0] != f.prev_last;
+    const bool first_break = lane == 0 || sk_differ<BYG>(f.hm[0], BYG ? f.prev_last + 32u : f.prev_last);
     f.c0 = first_break ? 0u : (r0 - f.ns0) % lmax;
     if (first_break)
         f.ns0 = r0;
@@ -244,7 +304,7 @@ __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
 
 // the same walk with the callback at EVERY row position (end = a record ends at this thread's row j; false for rows
 // that do not exist), so that the callback may use wave-wide operations
-template <int W, typename Emit>
+template <bool BYG, int W, typename Emit>
 __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
     u32 r0 = (u32)(threadIdx.x & 63) * 32;
@@ -254,10 +314,10 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Em
     for (int j = 0; j < 32; j++) {
         bool end = false;
         if ((u32)j < f.n_valid) {
-            if (j > 0 && f.hm[j] != f.hm[j - 1])
+            if (j > 0 && sk_differ<BYG>(f.hm[j], f.hm[j - 1]))
                 c = 0;
             const u32 nxt = j < 31 ? f.hm[j + 1] : f.next_first;
-            end = r0 + (u32)j + 1 == f.n_rows || nxt != f.hm[j] || c + 1 == lmax;
+            end = r0 + (u32)j + 1 == f.n_rows || sk_differ<BYG>(nxt, f.hm[j]) || c + 1 == lmax;
         }
         emit(j, end, r0 + (u32)j, c + 1, f.hm[j]);
         c = end ? 0u : c + 1;
@@ -266,7 +326,7 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Em
 
 // walks the thread's rows in order and calls emit(j, end_row, len, hmin) for every record that ENDS in them (j = the
 // row's index among the thread's 32: a constant once the loop is unrolled)
-template <int W, typename Emit>
+template <bool BYG, int W, typename Emit>
 __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &&emit)
 {
     u32 r0 = (u32)(threadIdx.x & 63) * 32;
@@ -275,11 +335,11 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         if ((u32)j < f.n_valid) {
-            if (j > 0 && f.hm[j] != f.hm[j - 1])
+            if (j > 0 && sk_differ<BYG>(f.hm[j], f.hm[j - 1]))
                 c = 0;                                     // (a break at j == 0 is already in c0)
             const u32 nxt = j < 31 ? f.hm[j + 1] : f.next_first;
             const bool last = r0 + (u32)j + 1 == f.n_rows;   // records are cut at the tile's end
-            const bool end = last || nxt != f.hm[j] || c + 1 == lmax;
+            const bool end = last || sk_differ<BYG>(nxt, f.hm[j]) || c + 1 == lmax;
             if (end) {
                 emit(j, r0 + (u32)j, c + 1, f.hm[j]);
                 c = 0;
@@ -293,11 +353,12 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &
 // ------------------------------------------------------------------------------------------------
 // sk_hist0: records per coarse digit of every chunk of rows (the histogram the generic prefix kernels take).  The
 // chunk's wave tiles go round the workgroup's four waves; the waves meet only at the histogram (LDS adds).
-template <int W>
+template <int W, bool BATCH>
 __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                          const u64 *__restrict__ words, u64 n_words, u64 first,
                                                          u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n /* digits of the root's split */,
-                                                         u32 *__restrict__ hist, u32 *__restrict__ accum /* or null */)
+                                                         u32 *__restrict__ hist, u32 *__restrict__ accum /* or null */,
+                                                         const u32 *__restrict__ marks, u64 n_mark_words)
 {
     __shared__ u32 h[SK_MAX_C0 + 64];             // (+ a word per lane for the adds that count nothing)
     if (blockIdx.x >= n_chunks)
@@ -310,23 +371,27 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
     for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, first + ch.off + t0, n_rows, lmax, mmask, nullptr);
+        sk_front<W, BATCH>(f, words, n_words, first + ch.off + t0, n_rows, lmax, mmask, nullptr, marks, n_mark_words);
         if (f.plain) {
-            // a record ends at every row whose successor has another minimum (lane 62's last row: the tile's end).  No
-            // branch per row: a lane whose row ends nothing adds to a word of its own behind the histogram.
+            // a record ends at every row whose successor has another minimum -- hash or position -- (lane 62's last row: the
+            // tile's end).  No branch per row: a lane whose row ends nothing adds to a word of its own behind the histogram.
+            // (sk_scatter0 cuts the same records whether its list of them overflows or not.)
             if (lane < 63) {
                 const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
 #pragma unroll
                 for (int j = 0; j < 32; j++) {
                     const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
                     const u32 d0 = sk_digit0(sk_digit_word(f.hm[j]), c0n);
-                    atomicAdd(&h[nxt != f.hm[j] ? d0 : (u32)SK_MAX_C0 + (u32)lane], 1u);
+                    atomicAdd(&h[nxt != f.hm[j] && (!BATCH || f.hm[j] != 0u) ? d0 : (u32)SK_MAX_C0 + (u32)lane], 1u);
                 }
             }
         } else {
-            sk_front_open<W>(f, lmax);
+            sk_front_open<true, W>(f, lmax);
             if (lane < 63)
-                sk_records<W>(f, lmax, [&](int, u32, u32, u32 hmin) { atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u); });
+                sk_records<true, W>(f, lmax, [&](int, u32, u32, u32 hmin) {
+                    if (!BATCH || (hmin >> 6) != 0u)
+                        atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u);
+                });
         }
     }
     __syncthreads();
@@ -346,13 +411,14 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
 // every bucket (histogram prefix), so a per-digit cursor in LDS hands out consecutive slots; with at most a few
 // dozen coarse digits the open cache lines of a workgroup are few and the 16-byte stores combine in L2.
 //   record = lo: bases 0..31 of the run; hi: bases 32..53 (bits 0..43) | (len-1) << 44 | d1 << 49 | d2 << 59
-template <int W>
+template <int W, bool BATCH>
 __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__restrict__ chunks, u32 n_chunks,
                                                             const u64 *__restrict__ words, u64 n_words, u64 first, int k,
                                                             u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n,
                                                             const u32 *__restrict__ hist, const u32 *__restrict__ tot,
                                                             ull2_t *__restrict__ recs, int dbg,
-                                                            u32 *__restrict__ slab /* or null: see below */)
+                                                            u32 *__restrict__ slab /* or null: see below */,
+                                                            const u32 *__restrict__ marks, u64 n_mark_words)
 {
     // slab != null: level 0 WITHOUT its histogram sweep.  slab[0 .. r0n) = slots a chunk reserves of every digit's region
     // (the host's estimate from a sampled histogram + slack), slab[SK_MAX_C0 + 16 d] = the digit's global cursor (starts
@@ -394,17 +460,21 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         const u64 tile_pos = first + ch.off + t0;
         const u32 fo = (u32)(tile_pos & 31);
         SkFront<W> f;
-        sk_front<W>(f, words, n_words, tile_pos, n_rows, lmax, mmask, wsh);
+        sk_front<W, BATCH>(f, words, n_words, tile_pos, n_rows, lmax, mmask, wsh, marks, n_mark_words);
         // The records that end in this tile (usually ~225) are listed in the wave's LDS list (ballot + prefix count per
         // row position: no atomics), and every lane then builds the payloads of its share -- building them where they end
         // would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the list
         // (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
         // fit (8 x 63 records).
         // list entry: hmin << 32 | start row << 16 | end row; start = 0xFFFF: the run started in an earlier lane (ns_tab)
-        auto build = [&](u32 wrun) {              // every lane builds and stores the records of its share of the list
+        // exact: the listed records are runs of one minimum, hash and position (a plain tile) -- they carry the minimum
+        // m-mer's offset; else (the general walk by hash alone) SK_REC_MULTI
+        auto build = [&](u32 wrun, bool exact) {  // every lane builds and stores the records of its share of the list
             if (!SK_DBG(2))
                 for (u32 e = (u32)lane; e < wrun; e += 64) {
                     const u64 en = wl[e];
+                    if (BATCH && (en >> 38) == 0)
+                        continue;                  // (a run of rows across a sequence start: not rows of the table)
                     const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
                     const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
                     const u32 end_row = (u32)en & 0xFFFFu;
@@ -428,7 +498,10 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                     } else {
                         hi &= ((u64)1 << (2 * (nb - 32))) - 1;
                     }
-                    hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59);
+                    // the minimum's position is relative to the first row of the lane that holds the record's last row
+                    const u32 mpos = (end_row & ~31u) + ((u32)(en >> 32) & SK_GPOS_MASK) - start;
+                    const u32 tag = exact ? (mpos & SK_POS_MASK) << (SK_POS_SHIFT - 32) : 1u << (SK_REC_MULTI_BIT - 32);
+                    hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59) | ((u64)tag << 32);
                     ull2_t r;
                     r.x = lo;
                     r.y = hi;
@@ -465,37 +538,45 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             ns_tab[lane] = wave_prev(wave_incl_max(start == 0xFFFFu ? 0u : start));
             sk_wave_fence();                       // list, words and starts written by other lanes of this wave
             if (wrun <= (u32)SKW_LIST) {
-                build(wrun);
+                build(wrun, true);
                 sk_wave_fence();                   // wsh / list are rewritten by the next tile
                 continue;
             }
         }
-        // the general walk (a partial tile, runs longer than a record holds, or a list that overflowed: four passes of
-        // eight row positions each always fit)
-        sk_front_open<W>(f, lmax);
-        for (int n_pass = f.plain ? 4 : 1, pass = 0; pass < n_pass; pass++) {
-            const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
-            u32 wrun = 0;
-            sk_records_all<W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
-                const bool end = end_any && j >= jlo && j < jhi;
-                const u64 b = __ballot(end);
-                if (end) {
-                    const u32 pos = wrun + (u32)__popcll(b & below);
-                    if (pos < (u32)SKW_LIST)
-                        wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 16) | (u64)end_row;
+        // the general walk: a partial tile or long runs of one hash (records by hash alone, cut every lmax rows), or a plain
+        // tile whose list overflowed (the SAME records as above -- sk_hist0 counted those -- in four passes of eight row
+        // positions each, which always fit)
+        auto walk = [&](auto byg_tag) {
+            constexpr bool BYG = decltype(byg_tag)::value;
+            sk_front_open<BYG, W>(f, lmax);
+            for (int n_pass = BYG ? 1 : 4, pass = 0; pass < n_pass; pass++) {
+                const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
+                u32 wrun = 0;
+                sk_records_all<BYG, W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
+                    const bool end = end_any && j >= jlo && j < jhi;
+                    const u64 b = __ballot(end);
+                    if (end) {
+                        const u32 pos = wrun + (u32)__popcll(b & below);
+                        if (pos < (u32)SKW_LIST)
+                            wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 16) | (u64)end_row;
+                    }
+                    wrun += (u32)__popcll(b);
+                });
+                if (wrun > (u32)SKW_LIST) {        // (only possible in a single pass)
+                    n_pass = 4;
+                    pass = -1;
+                    sk_wave_fence();
+                    continue;
                 }
-                wrun += (u32)__popcll(b);
-            });
-            if (wrun > (u32)SKW_LIST) {            // (only possible in a single pass)
-                n_pass = 4;
-                pass = -1;
-                sk_wave_fence();
-                continue;
+                sk_wave_fence();                   // list and words written by other lanes of this wave
+                build(wrun, !BYG);
+                sk_wave_fence();                   // wsh / list are rewritten by the next pass / tile
             }
-            sk_wave_fence();                       // list and words written by other lanes of this wave
-            build(wrun);
-            sk_wave_fence();                       // wsh / list are rewritten by the next pass / tile
-        }
+        };
+        if (f.plain)
+            walk(std::false_type{});
+        else
+            walk(std::true_type{});
     }
     if (slab) {
         if (dropped)
@@ -1345,7 +1426,15 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   gives every quad a thread, and every record writes its quads' owner entries itself -- no search.  Records and
 //   owner table live in LDS, so that nothing between two barriers waits for global memory: the next bucket's records
 //   are requested a whole bucket ahead.
-//   What bounds it (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
+//   RECORDS ARE TESTED BEFORE K-MERS (round 4).  Equal k-mers share their minimum m-mer and its offset inside the k-mer,
+//   so two records cut from plain tiles can hold an equal k-mer only if their m-mers are equal AND they agree around them
+//   (sk_records_share_kmer).  The bucket's ~300 records go into a small table keyed by the m-mer (linear probing: a record
+//   passes every earlier entry of its m-mer on the way to its own slot and is tested against each: ~1.4 pairs per record at
+//   3 Gbase, 0.1 at 250 Mbase); a record that shares a k-mer with no other is CLEAN: each of its k-mers is the only one of
+//   its kind in the bucket and is emitted with count 1 -- no hash, no probe, no slot.  Only the k-mers of the other records
+//   (copies on random sequence: a handful per million; repeats) go through the k-mer table below.  A SK_REC_MULTI record
+//   (low-complexity stretch, the end of the sequence) makes all records of its bucket take the k-mer table.
+//   What bounded it before (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
 //   (9.3 G wave instructions at 3 Gbase: VALU issue 77 % busy, the CU's scalar unit 47 %), not the LDS (23 % busy).
 //   Measured and dropped: the quad's four first probes issued back to back (more registers live, a spill); eight k-mers
 //   per thread at 512 threads (half the waves); a binary search over the prefix instead of the owner table; branch-free
@@ -1353,16 +1442,46 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   a per-lane `claimed` flag as a bool (it lives in scalar registers: +44 % SALU, 13.8 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
-constexpr int SKC_SLOTS = 236 * 64;              // 15104 four-byte slots (load 0.2 at 3000 keys): with the tables below 79.0 KiB, two workgroups per CU
+constexpr int SKC_SLOTS = 200 * 64;              // 12800 four-byte slots (load 0.23 if all of 3000 keys go in): with the tables below 76.7 KiB, two workgroups per CU
+constexpr int SKV_SLOTS = 1024;                  // eight-byte slots of the record table (at most SKC_MAXREC = 512 entries)
 constexpr int SKC_MAXREC = 512;                  // records of a bucket (a bucket of 3300 k-mers of random sequence has ~370)
 constexpr int SKC_KPT = 4;                       // k-mers per quad
 constexpr int SKC_MAXQ = SKC_NT;                 // quads of a bucket: one per thread (the selection sends buckets with more elsewhere)
+static_assert(SKV_SLOTS == SKC_NT, "the record table is cleared by one store per thread");
 constexpr u32 SKC_FREE = ~0u;                    // an empty slot
 
 // k-mer j of a record
 __device__ __forceinline__ u64 sk_record_kmer(const ull2_t rec, u32 j, u64 kmask)
 {
     return funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j) & kmask;
+}
+
+// bits [sh, sh + 64) of hi:lo, sh in 0 .. 127
+__device__ __forceinline__ u64 sk_shr128(u64 lo, u64 hi, u32 sh)
+{
+    return sh < 64u ? funnel(lo, hi, sh) : hi >> (sh - 64u);
+}
+
+// Could records A and B -- both cut from plain tiles (SK_REC_MULTI clear), their minimum m-mers equal, at offsets a and b --
+// hold an equal k-mer?  All k-mers of such a record have their leftmost minimum m-mer at the record's one place, and that
+// offset inside a k-mer is a function of the k-mer's content: equal k-mers K = A[j1 ..] = B[j2 ..] have a - j1 = b - j2.  So
+// the records can only agree where they are aligned at their m-mers, and K covers the m-mer, L' bases before it and R'
+// behind it with L' + R' = k - m: an equal k-mer exists iff the bases agree over L before and R behind the m-mer (as far
+// as BOTH records reach: ML, MR) with L + R >= k - m.  Exact, not a filter.
+__device__ __forceinline__ bool sk_records_share_kmer(const ull2_t A, u32 a, u32 nba, const ull2_t B, u32 b, u32 nbb, u32 m, u32 kmm)
+{
+    const u64 pm = ((u64)1 << 34) - 1;             // payload bits of the second word (at most 49 bases)
+    const u64 ah = A.y & pm, bh = B.y & pm;
+    const u32 ML = a < b ? a : b;
+    const u32 ra = nba - a - m, rb = nbb - b - m;
+    const u32 MR = ra < rb ? ra : rb;               // <= k - m <= 17
+    const u64 xr = (sk_shr128(A.x, ah, 2u * (a + m)) ^ sk_shr128(B.x, bh, 2u * (b + m))) & (((u64)1 << (2u * MR)) - 1);
+    const u32 R = xr ? (u32)__builtin_ctzll(xr) >> 1 : MR;
+    if (R + ML < kmm)
+        return false;
+    const u64 xl = (funnel(A.x, ah, 2u * (a - ML)) ^ funnel(B.x, bh, 2u * (b - ML))) & (((u64)1 << (2u * ML)) - 1);
+    const u32 L = xl ? ML - 1u - ((63u - (u32)__builtin_clzll(xl)) >> 1) : ML;
+    return L + R >= kmm;
 }
 
 __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
@@ -1387,6 +1506,11 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
     __shared__ u32 copy_seen[2];
+    // the record table: m-mer value | record index << 32 (all ones: free); rdirty[r]: record r shares a k-mer with another;
+    // bmulti: the bucket holds a SK_REC_MULTI record
+    __shared__ __attribute__((aligned(16))) u64 vtab[SKV_SLOTS];
+    __shared__ unsigned char rdirty[SKC_MAXREC];
+    __shared__ u32 bmulti[2];
     int tid = threadIdx.x;
     int lane = tid & 63, wave = tid >> 6;
     u32 lq = blockIdx.x;
@@ -1396,8 +1520,15 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         tab[q] = SKC_FREE;
     for (int q = tid; q < SKC_NT * SKC_KPT / 2; q += SKC_NT)
         cop2[q] = 0;
-    if (tid < 2)
+    if (tid < 2) {
         copy_seen[tid] = 0;
+        bmulti[tid] = 0;
+    }
+    vtab[tid] = ~(u64)0;                           // (SKV_SLOTS == SKC_NT)
+    if (tid < SKC_MAXREC)
+        rdirty[tid] = 0;
+    const u32 mlen = k >= 23 ? 15u : 13u;          // sk_minimizer_len
+    const u32 vmask = (1u << (2u * mlen)) - 1u, kmm = (u32)k - mlen;
     const u64 kmask = kmer_mask(k);
     u32 li = list[lq];
     u32 off = list_off[lq];                        // the bucket's output range is [off, off + its k-mers): the exclusive scan of
@@ -1493,9 +1624,41 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         // from a three-dword window of the record that moves on two bits per k-mer (three v_alignbit), slot and
         // fingerprint come from one 32-bit product (the slot through a full-rate 24-bit multiply), and the probe loop
         // carries the slot's byte address only -- what a claim leaves behind is assigned once, after the loop.
+        // ---- the bucket's records against each other (see the head of the kernel)
+        u32 vslot = ~0u;
+        if ((u32)tid < nd.len) {
+            const ull2_t me = lrec[tid];
+            const u32 yh = (u32)(me.y >> 32);
+            if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
+                bmulti[par] = 1u;
+            } else {
+                const u32 a = (yh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK;
+                const u32 nba = ((yh >> 12) & 31u) + (u32)k;                     // bases: len + k - 1
+                const u32 v = (u32)funnel(me.x, me.y & (((u64)1 << 34) - 1), 2u * a) & vmask;
+                const u64 mine = (u64)v | ((u64)(u32)tid << 32);
+                u32 slot = (v * 0x9E3779B1u) >> 22;
+                for (;;) {
+                    const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)mine);
+                    if (old == ~(u64)0)
+                        break;
+                    if ((u32)old == v) {                                         // an earlier record of the same m-mer
+                        const u32 oid = (u32)(old >> 32);
+                        const ull2_t ot = lrec[oid];
+                        const u32 oyh = (u32)(ot.y >> 32);
+                        if (sk_records_share_kmer(me, a, nba, ot, (oyh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK,
+                                                  ((oyh >> 12) & 31u) + (u32)k, mlen, kmm)) {
+                            rdirty[tid] = 1;
+                            rdirty[oid] = 1;
+                        }
+                    }
+                    slot = (slot + 1u) & (u32)(SKV_SLOTS - 1);
+                }
+                vslot = slot;
+            }
+        }
         u32 ckl[KEEP], ckh[KEEP];
         u32 cslot[KEEP];                           // byte address of the claimed slot
-        u32 c_mask = 0;
+        u32 c_mask = 0, s_mask = 0;                // k-mers of the quad that are groups of their own / that hold a slot of the table
         // (only positions whose c_mask bit is set are ever used: the others stay whatever their registers hold -- defined
         // for the compiler by an empty asm, so that no instruction initialises them: 12 moves per thread and bucket)
 #pragma unroll
@@ -1504,20 +1667,22 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             asm volatile("" : "=v"(ckh[q]));
             asm volatile("" : "=v"(cslot[q]));
         }
-        if ((u32)tid < n_quads) {
+        const bool has_quad = (u32)tid < n_quads;
+        u32 qrec = 0, rl = 0, j0 = 0;              // the quad's record, its k-mers, the quad's first
+        if (has_quad) {
             const u32 e = ownq[tid];
-            const ull2_t rec = lrec[e & 511u];
+            qrec = e & 511u;
+            const ull2_t rec = lrec[qrec];
             const u32 p0 = (u32)rec.x, p1 = (u32)(rec.x >> 32), p2 = (u32)rec.y, p3h = (u32)(rec.y >> 32);
-            const u32 rl = ((p3h >> 12) & 31u) + 1u;
+            rl = ((p3h >> 12) & 31u) + 1u;
             const u32 p3 = p3h & 0xFFFu;
-            const u32 j0 = (e >> 9) * SKC_KPT;
+            j0 = (e >> 9) * SKC_KPT;
             const bool up = j0 >= 16;                            // the quad starts in the record's second dword
             const u32 sh = (2 * j0) & 31u;
             const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2, a3 = up ? 0u : p3;
             u32 w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh),
                 w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
             const u32 hmask = (u32)(kmask >> 32);                // (k >= 21: the low dword is whole)
-            const u32 id0 = (u32)tid << 2;
             // all four keys of the quad first, straight into the registers that keep them (the window moves on two bits per
             // k-mer whether the position exists or not: no copies where the branches of the inserts meet)
 #pragma unroll
@@ -1528,6 +1693,17 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                 w1 = __builtin_amdgcn_alignbit(w2, w1, 2);
                 w2 >>= 2;
             }
+        }
+        __syncthreads();                           // R: every record tested
+        if (vslot != ~0u)
+            vtab[vslot] = ~(u64)0;                 // (the table is clean again for the next bucket)
+        if (has_quad) {
+            const u32 id0 = (u32)tid << 2;
+            const u32 nk = rl - j0 < (u32)SKC_KPT ? rl - j0 : (u32)SKC_KPT;
+            if (!(bmulti[par] | rdirty[qrec])) {
+                // a clean record: each of its k-mers is the only one of its kind in the bucket
+                c_mask = (1u << nk) - 1u;
+            } else
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
                 if (j0 + (u32)q < rl) {
@@ -1545,6 +1721,7 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                             const u32 old = atomicCAS(reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + sa), SKC_FREE, word);
                             if (old == SKC_FREE) {
                                 c_mask |= 1u << q;
+                                s_mask |= 1u << q;
                                 break;
                             }
                             if ((old ^ word) < 4096u) {
@@ -1588,8 +1765,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             pkl[q] = ckl[q];
             pkh[q] = ckh[q];
             pc[q] = 0;
-            if ((c_mask >> q) & 1u) {
+            if ((c_mask >> q) & 1u)
                 pc[q] = 1u;
+            if ((s_mask >> q) & 1u) {
                 *reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + cslot[q]) = SKC_FREE;
                 if (any_copy) {
                     const u32 copies = cop16[(u32)tid * SKC_KPT + (u32)q];
@@ -1608,8 +1786,11 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         p_copy = any_copy;
         if (tid == 0) {
             my_groups += D;
-            copy_seen[par ^ 1] = 0;                // (the other parity's flag: its bucket is done with it)
+            copy_seen[par ^ 1] = 0;                // (the other parity's flags: its bucket is done with them)
+            bmulti[par ^ 1] = 0;
         }
+        if (tid < SKC_MAXREC)
+            rdirty[tid] = 0;                       // (read between R and B only; the next bucket's tests start behind A2)
         have_prev = true;
         par ^= 1;
         if (!has_next)
@@ -2204,17 +2385,18 @@ static int sk_dbg()
 
 // ------------------------------------------------------------------------------------------------
 // launchers
-template <int W>
+template <int W, bool BATCH>
 static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk *chunks, const u64 *words, u64 n_words,
                          u64 first, int k, u32 lmax, u32 mmask, u32 c0n, u32 b1mask, u32 r0n, u32 *hist, const u32 *tot, void *recs,
-                         u32 *aux)
+                         u32 *aux, const u32 *marks, u64 n_mark_words)
 {
     if (scatter)
-        hipLaunchKernelGGL(sk_scatter0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           k, lmax, mmask, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg(), aux);
+        hipLaunchKernelGGL((sk_scatter0_kernel<W, BATCH>), dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
+                           k, lmax, mmask, c0n, b1mask, r0n, hist, tot, reinterpret_cast<ull2_t *>(recs), sk_dbg(), aux, marks,
+                           n_mark_words);
     else
-        hipLaunchKernelGGL(sk_hist0_kernel<W>, dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
-                           lmax, mmask, c0n, b1mask, r0n, hist, aux);
+        hipLaunchKernelGGL((sk_hist0_kernel<W, BATCH>), dim3(n_chunks), dim3(SK_NT), 0, s, chunks, n_chunks, words, n_words, first,
+                           lmax, mmask, c0n, b1mask, r0n, hist, aux, marks, n_mark_words);
 }
 
 // The minimizer's length m: 15 for k >= 23 (windows of 9 .. 18 m-mers), 13 for k = 21 and 22 (windows of 9 and 10: runs of
@@ -2224,7 +2406,8 @@ int sk_min_k() { return 21; }
 int sk_minimizer_len(int k) { return k >= 23 ? 15 : 13; }
 
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
-                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s, u32 *aux)
+                            u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s, u32 *aux,
+                            const u32 *marks, u64 n_mark_words)
 {
     if (n_chunks == 0)
         return hipSuccess;
@@ -2237,7 +2420,10 @@ hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, con
     const u32 b1mask = (1u << b1bits) - 1, r0n = 1u << r0bits;
     if (r0n > (u32)SK_MAX_C0)
         return hipErrorInvalidValue;
-#define SK_CASE(W_) case W_: launch_front<W_>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs, aux); break;
+#define SK_CASE(W_) case W_: \
+        if (marks) launch_front<W_, true>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs, aux, marks, n_mark_words); \
+        else launch_front<W_, false>(scatter, n_chunks, s, chunks, words, n_words, first, k, lmax, mmask, c0n, b1mask, r0n, hist, tot, recs, aux, nullptr, 0); \
+        break;
     switch (w) {
         SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16) SK_CASE(17) SK_CASE(18)
     default: return hipErrorInvalidValue;

@@ -187,6 +187,18 @@ int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
 int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                                  uint64_t first, uint64_t count, dnagpu_hist **out);
 int dnagpu_hist_is_sorted(const dnagpu_hist *h);
+/* GROUP BY kmer, count(*) over a TABLE of sequences -- the reference's second counting shape,
+ *   SELECT k.kmer, count(*) FROM dna_sequences d, LATERAL generate_kmers(d.sequence, K) AS k(kmer) GROUP BY k.kmer
+ * (test.sql:140-150: one generate_kmers call per row of the table, dna.c:743-837; data/create_dna.py:36-49 writes such
+ * tables of read-like rows).  The table travels as ONE packed stream `dna` (the sequences' bases back to back, no
+ * padding) and seq_starts[0 .. n_seqs] (host memory): the first base of every sequence, seq_starts[0] = 0,
+ * seq_starts[n_seqs] = dnagpu_dna_length(dna), ascending (equal neighbours: an empty sequence).  The rows are those of
+ * every sequence's own generate_kmers: no k-mer spans two sequences, a sequence shorter than k has none (the 64-bit
+ * restatement of dna.c:781).  Same result object as dnagpu_count_kmers_unordered (group order unspecified;
+ * dnagpu_hist_is_sorted tells); dnagpu_hist_total = the rows of the table.  At most 2^32 - 1 bases per call: callers
+ * that stream larger tables count batch by batch and add the histograms up (dnagpu_hist_merge). */
+int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs,
+                             int k, dnagpu_hist **out);
 /* Same over an arbitrary array of n keys of k bases already in device memory.  dev_keys is used as
  * scratch and its contents are unspecified afterwards. */
 int dnagpu_count_keys(dnagpu_ctx *ctx, uint64_t *dev_keys, uint64_t n, int k, dnagpu_hist **out);

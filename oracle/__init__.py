@@ -38,6 +38,8 @@ def lib():
         L.orc_generate_kmers_count.argtypes = [C.c_uint64, C.c_int, u64p]
         for f in (L.orc_generate_kmers, L.orc_generate_kmers_fast):
             f.argtypes = [u64p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, u64p]
+        L.orc_table_kmers_count.argtypes = [u64p, C.c_uint64, C.c_int, u64p]
+        L.orc_generate_kmers_table.argtypes = [u64p, C.c_uint64, u64p, C.c_uint64, C.c_int, C.c_int, u64p]
         L.orc_kmer_eq.argtypes = [C.c_int32, C.c_uint64, C.c_int32, C.c_uint64]
         L.orc_kmer_hash.restype = C.c_uint32
         L.orc_kmer_hash.argtypes = [C.c_uint64]
@@ -136,6 +138,19 @@ def generate_kmers(words, n_bases, k, first=0, count=None, faithful=True):
     w = np.ascontiguousarray(words, dtype=np.uint64)
     fn = lib().orc_generate_kmers if faithful else lib().orc_generate_kmers_fast
     _chk(fn(_p(w), n_bases, k, first, count, _p(out)))
+    return out
+
+
+def generate_kmers_table(words, starts, k, faithful=False):
+    """rows of generate_kmers(seq, k) for every sequence of a table, in table order (test.sql:140-150): `words` = the
+    concatenated packed stream, starts[i] = first base of sequence i, starts[-1] = all bases"""
+    st = np.ascontiguousarray(starts, dtype=np.uint64)
+    n_seqs = len(st) - 1
+    rows = C.c_uint64()
+    _chk(lib().orc_table_kmers_count(_p(st), n_seqs, k, C.byref(rows)))
+    out = np.empty(rows.value, dtype=np.uint64)
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    _chk(lib().orc_generate_kmers_table(_p(w), int(st[-1]), _p(st), n_seqs, k, 1 if faithful else 0, _p(out)))
     return out
 
 

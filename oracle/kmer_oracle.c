@@ -174,6 +174,49 @@ int orc_generate_kmers_fast(const uint64_t *words, uint64_t n_bases, int k,
     return ORC_OK;
 }
 
+/* The second counting shape of the reference: FROM a table of sequences, LATERAL generate_kmers(d.sequence, k)
+ * (test.sql:140-150: one SRF call per row of the table, every call per dna.c:743-837, so no k-mer spans two rows).
+ * The table is given as ONE concatenated packed stream and the first base of every sequence (starts[0 .. n_seqs], starts[0]
+ * = 0, starts[n_seqs] = n_bases, ascending; equal neighbours = an empty sequence): sequence i yields the rows of
+ * generate_kmers over its own bases -- the windows [starts[i], starts[i] + len_i - k] of the stream -- in table order;
+ * a sequence shorter than k yields none (the 64-bit restatement of dna.c:781, as in orc_generate_kmers).  faithful != 0
+ * takes the per-base form of dna.c:803-825 for every row.  out_keys: room for orc_table_kmers_count rows. */
+int orc_table_kmers_count(const uint64_t *starts, uint64_t n_seqs, int k, uint64_t *n_rows)
+{
+    uint64_t probe, rows = 0;
+    int rc = orc_generate_kmers_count(0, k, &probe);           /* (the k check of dna.c:771-773) */
+    if (rc)
+        return rc;
+    for (uint64_t i = 0; i < n_seqs; i++) {
+        uint64_t len = starts[i + 1] - starts[i];
+        if (len >= (uint64_t)k)
+            rows += len - (uint64_t)k + 1;
+    }
+    *n_rows = rows;
+    return ORC_OK;
+}
+
+int orc_generate_kmers_table(const uint64_t *words, uint64_t n_bases, const uint64_t *starts, uint64_t n_seqs, int k,
+                             int faithful, uint64_t *out_keys)
+{
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n_seqs; i++) {
+        if (starts[i + 1] < starts[i] || starts[i + 1] > n_bases)
+            return ORC_ERR_NOMEM;
+        uint64_t len = starts[i + 1] - starts[i];
+        if (len < (uint64_t)k)
+            continue;
+        uint64_t rows = len - (uint64_t)k + 1;
+        /* the sequence's own rows: the stream is cut behind its last base, so that the row rule of dna.c:781 is its own */
+        int rc = faithful ? orc_generate_kmers(words, starts[i + 1], k, starts[i], rows, out_keys + at)
+                          : orc_generate_kmers_fast(words, starts[i + 1], k, starts[i], rows, out_keys + at);
+        if (rc)
+            return rc;
+        at += rows;
+    }
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------ operators */
 
 /* dna.c:655-668 */

@@ -80,6 +80,13 @@ int orc_generate_kmers(const uint64_t *words, uint64_t n_bases, int k,
 int orc_generate_kmers_fast(const uint64_t *words, uint64_t n_bases, int k,
                             uint64_t first, uint64_t count, uint64_t *out_keys);
 
+/* generate_kmers over a TABLE of sequences (test.sql:140-150: LATERAL generate_kmers(d.sequence, k) per row): one
+ * concatenated packed stream + the first base of every sequence (n_seqs + 1 entries, the last = n_bases); no k-mer
+ * spans two sequences, a sequence shorter than k yields no row. */
+int orc_table_kmers_count(const uint64_t *starts, uint64_t n_seqs, int k, uint64_t *n_rows);
+int orc_generate_kmers_table(const uint64_t *words, uint64_t n_bases, const uint64_t *starts, uint64_t n_seqs, int k,
+                             int faithful, uint64_t *out_keys);
+
 /* ---- operators ---- */
 int orc_kmer_eq(int32_t len1, uint64_t bits1, int32_t len2, uint64_t bits2);       /* dna.c:655-668 */
 uint32_t orc_kmer_hash(uint64_t bits);                                             /* dna.c:722-735 */

@@ -1100,6 +1100,74 @@ def test_pool_guard_bands_catch_a_write_past_the_end(pkg):
         d.free()
 
 
+# ------------------------------------------------------------------ GROUP BY over a table of sequences (test.sql:140-150)
+
+def table_of_sequences(seed, n_seqs, lo, hi):
+    """n_seqs sequences of lo .. hi bases back to back in one packed stream (+ a few empty ones and some shorter than any k):
+    -> (words, starts)"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, n_seqs)
+    if n_seqs >= 10:
+        lens[rng.integers(0, n_seqs, max(1, n_seqs // 50))] = 0          # empty rows
+        lens[rng.integers(0, n_seqs, max(1, n_seqs // 50))] = rng.integers(1, 8)
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(starts[-1])
+    return orc.synth_words(seed, n), starts
+
+
+@pytest.mark.parametrize("n_seqs,lo,hi", [(1, 5000, 5000), (2, 50, 10_000), (1000, 50, 10_000), (1_000_000, 50, 250),
+                                         (200_000, 140, 160), (3, 1, 40), (40_000, 20, 64)])
+def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
+    """dnagpu_count_kmers_batch: GROUP BY kmer over FROM table, LATERAL generate_kmers(sequence, k) -- every sequence's own
+    rows, none across two sequences, none for a sequence shorter than k -- against the oracle's per-sequence
+    generate_kmers + hash aggregate.  Long k-mers through the super-k-mer engine (forced for the short tables), short
+    ones and the default choice through the compacted keys; k = 10 is the reference's own (test.sql:143)."""
+    words, starts = table_of_sequences(0xBA7C4 + n_seqs, n_seqs, lo, hi)
+    n = int(starts[-1])
+    d = ctx.upload(words, n)
+    for k in (31, 21, 32, 25, 10, 3):
+        ok, oc = orc.count_keys(orc.generate_kmers_table(words, starts, k))
+        for forced in (True, False):
+            if forced and k < 21:
+                continue
+            ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_SLAB0 if forced else 0)
+            try:
+                h = ctx.count_kmers_batch(d, starts, k)
+            finally:
+                ctx.set_debug(0)
+            what = f"table of {n_seqs} sequences ({lo}..{hi} bases), k={k}, {'records' if forced else 'default engine'}"
+            assert h.total == int(oc.sum()), what
+            if h.is_sorted:
+                check_hist(h, ok, oc, what)
+            else:
+                check_hist_unordered(h, ok, oc, what)
+            h.free()
+    d.free()
+
+
+def test_count_kmers_batch_is_the_plain_count_for_one_sequence_and_checks_its_arguments(ctx, pkg):
+    n = 300_000
+    words = orc.synth_words(77, n)
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_kmers(words, n, 31)
+    h = ctx.count_kmers_batch(d, [0, n], 31)
+    check_hist(h, ok, oc, "one sequence") if h.is_sorted else check_hist_unordered(h, ok, oc, "one sequence")
+    h.free()
+    for bad in ([0, n - 1], [1, n], [0, 200, 100, n], [0]):
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            ctx.count_kmers_batch(d, bad, 31)
+        assert ei.value.code == 5                  # DNAGPU_ERR_BAD_ARG
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.count_kmers_batch(d, [0, n], 33)
+    assert ei.value.code == 1 and "between 1 and 32" in str(ei.value)      # dna.c:773
+    h = ctx.count_kmers_batch(d, [0, 10, 20, n], 31) if False else ctx.count_kmers_batch(d, [0, 10, 20, 30, n - 5, n], 32)
+    keys = orc.generate_kmers_table(words, np.array([0, 10, 20, 30, n - 5, n], dtype=np.uint64), 32)
+    ok, oc = orc.count_keys(keys)
+    check_hist(h, ok, oc, "short sequences around a long one") if h.is_sorted else check_hist_unordered(h, ok, oc, "short sequences around a long one")
+    h.free()
+    d.free()
+
+
 # ------------------------------------------------------------------ multi-GPU count through the C-ABI (one process)
 
 def rank_device_maps(pkg, n_ranks):
@@ -1160,6 +1228,8 @@ def _count_multi_unordered_case(pkg, n_ranks, parts, devices, where, via_rccl, n
     shared = len(set(devices)) < len(devices)
     with pkg.Multi(devices, pkg.MULTI_COPY if shared else pkg.MULTI_AUTO) as m:
         m.set_parts(parts)
+        for c in m.ranks:
+            c.set_profiling(True)           # (rank_phase_times below)
         if via_rccl:
             if m.transport != "rccl":
                 return                      # (no communicator on this box: the copy transport was the first run)
@@ -1196,8 +1266,10 @@ def _count_multi_unordered_case(pkg, n_ranks, parts, devices, where, via_rccl, n
                     assert m.exchange_transport == ("rccl-sendrecv" if via_rccl else "peer-copy"), where
                     if count is None:           # (a window may lie in one rank's chunk: then nothing travels)
                         assert (lt["bytes_moved"] > 0) == (n_ranks > 1)
-                    names = [nm for nm, _ in m.rank_phase_times(0)]
-                    assert any(nm.startswith("sk_scatter0") for nm in names) and "sk_count" in names, names
+                    # a rank's phases = its record pass (level 0), then its owner phase (some owner counts with sk_count)
+                    names = [[nm for nm, _ in m.rank_phase_times(r)] for r in range(n_ranks)]
+                    assert any(nm.startswith("sk_scatter0") for nm in names[0]), names[0]
+                    assert any("sk_count" in nms for nms in names), names
                 for h in hs:
                     h.free()
             m.dna_free(d)

@@ -219,3 +219,22 @@ def test_wire_image_known_answers():
     for bad_len in (0, 33, -1):
         with pytest.raises(orc.OracleError):
             orc.kmer_from_wire(orc.kmer_to_wire(bad_len, 1))
+
+
+def test_table_of_sequences_rows_are_each_sequences_own():
+    """generate_kmers over a table (test.sql:140-150: LATERAL generate_kmers(d.sequence, k) per row): the rows of the
+    concatenated stream restricted to windows inside one sequence == every sequence's own rows through the text path
+    (dna_in + generate_kmers), faithful and fast forms; the reference's literal of test.sql:95 among the rows."""
+    seqs = ["ATCGATCGATCGATCGACG", "ACG", "", "ACGTACGTACGTAG", "T" * 40, "GATTACA"]
+    w, n = orc.dna_encode("".join(seqs))
+    starts = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    assert n == int(starts[-1])
+    for k in (1, 3, 5, 8, 14, 19, 20):
+        want = [orc.generate_kmers(*orc.dna_encode(s), k) for s in seqs if len(s) >= k]
+        want = np.concatenate(want) if want else np.empty(0, dtype=np.uint64)
+        for faithful in (True, False):
+            got = orc.generate_kmers_table(w, starts, k, faithful=faithful)
+            assert np.array_equal(got, want), (k, faithful)
+    keys, counts = orc.count_keys(orc.generate_kmers_table(w, starts, 5))
+    groups = {orc.kmer_decode(a, 5): int(b) for a, b in zip(keys, counts)}
+    assert groups["ATCGA"] == 4 and groups["TTTTT"] == 36 and groups["ACGTA"] == 3     # test.sql:95's 4 + the other rows

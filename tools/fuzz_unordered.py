@@ -28,6 +28,31 @@ with pkg.Context(0) as ctx:
         else:
             motif = 0
             words = orc.synth_words(seed, n)
+        # near-copies: the second half repeats the first with point changes every ~10 / 30 / 100 / 300 bases -- records
+        # that share their minimizer and agree over PART of their k-mers (sk_count's record-against-record test: the
+        # boundary "bases agree over at least k - m around the m-mer")
+        mutated = 0
+        if rng.random() < 0.3 and len(words) > 8:
+            mutated = int(rng.choice([10, 30, 100, 300]))
+            words = words.copy()
+            nw = len(words)
+            half = nw // 2
+            shift_words = int(rng.integers(0, 3))       # (the copy need not start on the same word phase ...)
+            words[half:half + half - shift_words] = words[shift_words:half]
+            n_mut = max(1, (half * 32) // mutated)
+            pos = rng.integers(half * 32, nw * 32, n_mut)
+            for pb in pos:
+                wi, sh = int(pb) >> 5, 2 * (int(pb) & 31)
+                words[wi] ^= np.uint64(int(rng.integers(1, 4)) << sh)
+            if rng.random() < 0.5:                      # (... nor on the same base phase: one base inserted at the half)
+                carry = np.uint64(int(rng.integers(0, 4)))
+                for wi in range(half, nw):
+                    nxt = words[wi] >> np.uint64(62)
+                    words[wi] = (words[wi] << np.uint64(2)) | carry
+                    carry = nxt
+            r = n % 32
+            if r:
+                words[-1] &= np.uint64((1 << (2 * r)) - 1)
         planted = 0
         if rng.random() < 0.4 and len(words) > 8:
             words = words.copy()
@@ -73,7 +98,7 @@ with pkg.Context(0) as ctx:
         d.free()
         if not good:
             bad += 1
-            print(f"MISMATCH case {c}: n={n} k={k} seed={seed} motif={motif} planted={planted} first={first} count={count} flags={flags}",
+            print(f"MISMATCH case {c}: n={n} k={k} seed={seed} motif={motif} mutated={mutated} planted={planted} first={first} count={count} flags={flags}",
                   flush=True)
         if c % 25 == 24:
             print(f"... {c + 1} cases, {bad} mismatches, {time.time() - t_start:.0f} s", flush=True)
