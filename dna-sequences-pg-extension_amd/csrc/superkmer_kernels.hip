@@ -141,7 +141,7 @@ __device__ __forceinline__ u32 wave_prev(u32 x) { return (u32)__builtin_amdgcn_u
 //   BATCH (a table of sequences in one packed stream, dnagpu_count_kmers_batch: `marks` = one bit per base, set where a
 //   sequence starts): an m-mer that reaches across a sequence start hashes to 0.  A k-mer's window holds such an m-mer
 //   exactly when the k-mer itself reaches across a start, so the rows that are NOT rows of the table -- and only they --
-//   have the minimum 0; they form runs of their own, which are counted and stored nowhere.
+//   have a minimum below 64 (hash part 0); they form runs of their own, which are counted and stored nowhere.
 template <int W>
 struct SkFront {
     u32 hm[32];
@@ -382,7 +382,9 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
                 for (int j = 0; j < 32; j++) {
                     const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
                     const u32 d0 = sk_digit0(sk_digit_word(f.hm[j]), c0n);
-                    atomicAdd(&h[nxt != f.hm[j] && (!BATCH || f.hm[j] != 0u) ? d0 : (u32)SK_MAX_C0 + (u32)lane], 1u);
+                    // (BATCH: a minimum below 64 is an m-mer across a sequence start -- 0 in its own lane, 32 + j seen from the
+                    // lane before: such runs are counted and stored nowhere)
+                    atomicAdd(&h[nxt != f.hm[j] && (!BATCH || f.hm[j] >= 64u) ? d0 : (u32)SK_MAX_C0 + (u32)lane], 1u);
                 }
             }
         } else {
