@@ -1785,7 +1785,10 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     Node *fn = nullptr;
     RC_TRY(ps.alloc((size_t)l1.n_next * 16 + lh.n_next, &fn));
     prof_mark(ctx, "sk_regroup");
-    HIP_TRY(launch_sk_regroup(l1.next, l1.n_next, rec1, rec0, fn, st));
+    bool any_long = false;                       // (mid buckets of more than one regroup tile: repeats)
+    for (u32 i = 0; i < l1.n_next && !any_long; i++)
+        any_long = rcn[i] > (u32)sk_regroup_tile();
+    HIP_TRY(launch_sk_regroup(l1.next, l1.n_next, rec1, rec0, fn, any_long, st));
     if (lh.n_next)
         HIP_TRY(launch_sk_heavy_finals(lh.next, lh.n_next, kcount2, fn + (size_t)l1.n_next * 16, st));
     if (nh == 0 || !heavy_expand)

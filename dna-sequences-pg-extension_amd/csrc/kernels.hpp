@@ -222,7 +222,8 @@ hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const 
                                  u32 n_slices, int k, u64 *keys, hipStream_t s);
 // every mid bucket's records regrouped by d2 from src into the same range of dst; out_nodes[16 i + j] = final bucket:
 // start / len in records, child_base = its k-mers
-hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s);
+int sk_regroup_tile();   // records one workgroup regroups in one go; longer mid buckets need any_long (a second kernel)
+hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, bool any_long, hipStream_t s);
 // final buckets list[0..n_list) (indices into fin) counted from their records in an LDS hash table; groups appended
 // at *cursor, seg_off / seg_cnt[bucket] = where they went
 // list_off[i] = first output slot of bucket list[i] (its range is as long as its k-mers; slots past its distinct keys are

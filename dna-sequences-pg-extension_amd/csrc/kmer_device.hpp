@@ -130,6 +130,29 @@ __device__ __forceinline__ u32 wave_sum(u32 x)
     return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
 }
 
+// In-place exclusive scan of arr[0..n), n <= NT, in LDS by NT threads (one element per thread); returns the total.  The
+// caller has synchronised before the call; the function synchronises before returning.  tid = the caller's thread index
+// (callers that keep it opaque per tile -- so that nothing derived from it is held across their tile loops -- pass that one).
+template <int NT>
+__device__ __forceinline__ u32 block_scan_small(u32 *arr, int n, u32 *wtmp, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const u32 v = tid < n ? arr[tid] : 0;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63)
+        wtmp[wave] = inc;
+    __syncthreads();
+    // every wave scans the (at most 16) wave totals itself: one LDS read, one DPP scan
+    const u32 ws = wave_incl_scan(lane < NT / 64 ? wtmp[lane] : 0u);
+    const int wv1 = __builtin_amdgcn_readfirstlane(wave);
+    const u32 total1 = (u32)__builtin_amdgcn_readlane((int)ws, NT / 64 - 1);
+    const u32 wbase1 = wv1 ? (u32)__builtin_amdgcn_readlane((int)ws, wv1 - 1) : 0u;
+    if (tid < n)
+        arr[tid] = wbase1 + inc - v;
+    __syncthreads();
+    return total1;
+}
+
 // In-place exclusive scan of arr[0..n) in LDS by NT threads; returns the total.  The caller has
 // synchronised before the call; the function synchronises before returning.
 template <int NT>

@@ -731,11 +731,12 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
     }
 }
 
-// sk_scatter1: tiles of 8192 records, ranked by d1 in LDS and copied to their mid buckets in sorted order, 16 bytes per
+// sk_scatter1: tiles of 8192 records, grouped by d1 in LDS and copied to their mid buckets in sorted order, 16 bytes per
 // lane (16 records per digit and tile on average: 256-byte runs).  Full tiles keep their records in registers between the
 // one read and the staging; the chunk's last, partial tile ranks an index list and gathers.
 constexpr int SK1_ITEMS = 8;
 constexpr int SK1_TILE = SK1_NT * SK1_ITEMS;
+constexpr int SK1_STAGE = SK1_TILE / 2 + 64;     // records the stage holds: half a tile and a digit's worth of slack
 // SPEC (level 1 without its histogram): the mid buckets are REGIONS of the destination buffer -- spec[2 node] = start of
 // the node's first, spec[2 node + 1] = records each holds, the cursors start at the regions' starts (sk_spec_*_kernel below)
 // -- and the sweep counts the k-mers per mid bucket itself (kcount).  A record that does not fit its region is dropped and
@@ -749,12 +750,17 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                                                              u32 *__restrict__ over)
 {
     __shared__ u32 cnt[ROW_STRIDE];
-    __shared__ u32 gpos[ROW_STRIDE];
+    // gadj[d]: where the tile's sorted slot sl of digit d goes = gadj[d] + sl (the digit's base in the destination minus its
+    // offset in the tile).  gpos[d] (only without global cursors: the by-d2 split of heavy buckets): the chunk's running
+    // position in digit d.
+    __shared__ u32 gadj[ROW_STRIDE];
+    __shared__ u32 gpos[SPEC ? 1 : ROW_STRIDE];
     __shared__ u32 kcs[SPEC ? ROW_STRIDE : 1];   // SPEC: k-mers of the chunk's records per digit
-    // a full tile: half of its records at a time, in sorted order (64 KB); a partial tile: the index list (16 KB of it)
-    __shared__ __attribute__((aligned(16))) ull2_t stage[SK1_TILE / 2];
+    // a full tile: about half of its records at a time, in sorted order; a partial tile: the index list (16 KB of it)
+    __shared__ __attribute__((aligned(16))) ull2_t stage[SK1_STAGE];
     unsigned short *idx = reinterpret_cast<unsigned short *>(stage);
     __shared__ u32 wtmp[SK1_NT / 64];
+    __shared__ u32 split[4];                       // a full tile's halves: [0] first digit of the second, [1] its offset, [2] skew
     if (blockIdx.x >= n_chunks)
         return;
     int tid = threadIdx.x;
@@ -763,15 +769,15 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     const u32 R = 1u << nd.split;
     const u32 *hrow = hist + (u64)blockIdx.x * ROW_STRIDE;
     const u32 *trow = tot + (u64)nd.chunk_base * ROW_STRIDE;          // absolute base of every digit of the node
-    if (!gcur)
-        for (u32 d = tid; d < R; d += SK1_NT)
-            gpos[d] = trow[d] + hrow[d];
     // gcur != null: the node's digits have GLOBAL cursors (a copy of `tot`: they start at the digits' absolute bases) and
     // every tile reserves its slots there, one returning add per digit, in flight while the tile is staged.  The chunks of a
     // node then fill a mid bucket in arrival order instead of each into a range of its own: a run's partial first and last
     // cache lines are completed by whichever workgroup writes to the bucket next, soon, while they are still in L2, and
     // the per-tile cursor update with its barrier is gone (3.27 -> 2.92 ms at 3 Gbase).  ~300 adds per address and count.
     u32 *gc = gcur ? gcur + (u64)nd.chunk_base * ROW_STRIDE : nullptr;
+    if (!SPEC && !gc)
+        for (u32 d = tid; d < R; d += SK1_NT)
+            gpos[d] = trow[d] + hrow[d];
     const ull2_t *src = src_all + (u64)nd.start + ch.off;
     const u32 dmask = R - 1;
     u32 reg0 = 0, rcap = ~0u;                      // SPEC: digit d's region is [reg0 + d rcap, reg0 + (d + 1) rcap)
@@ -782,71 +788,105 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
         for (u32 d = tid; d < R; d += SK1_NT)
             kcs[d] = 0;
     }
+    // after the tile's digit counts have become offsets (cnt[d]; cnt[R] = the tile's records): digit tid's slots in the
+    // destination -- reserved from its global cursor, or the chunk's own running position -- as gadj[tid]
+    auto place_digits = [&]() {
+        if ((u32)tid < R) {
+            const u32 lo = cnt[tid], c = cnt[tid + 1] - lo;
+            u32 base = 0;
+            if (gc) {
+                if (c)
+                    base = atomicAdd(&gc[tid], c);
+                if (SPEC && c && (u64)base + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
+                    dropped = true;
+            } else if (!SPEC) {
+                base = gpos[tid];
+                gpos[tid] = base + c;
+            }
+            gadj[tid] = base - lo;
+        }
+    };
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
         asm volatile("" : "+v"(tid));              // (thread-derived addresses recomputed per tile, not held: the kernel lives on 64 registers)
         for (u32 d = tid; d <= R; d += SK1_NT)     // (bin R: NULL records -- unused slots of a slab sweep -- sort behind all digits)
             cnt[d] = 0;
+        if (tid == 0) {
+            split[0] = R;                          // (a tile of at most SK1_STAGE records: one half)
+            split[2] = 0;
+        }
         __syncthreads();
-        if (n_tile == (u32)SK1_TILE) {
+        bool gather = n_tile != (u32)SK1_TILE, placed = false;
+        if (!gather) {
             // ---- a full tile (all tiles of a chunk but its last): every record is read ONCE, 16 bytes per lane and all
-            // eight of a thread in flight; it waits in registers while its sorted position in the tile is found, goes
-            // through LDS (half a tile at a time) into sorted order, and leaves in runs -- 16 bytes per lane, consecutive
-            // lanes to consecutive addresses.  (Reading the digits first and gathering the records by index afterwards --
-            // the partial tile's way below -- brings every record in twice: 16 GB moved for 10.7.)
+            // eight of a thread in flight; it waits in registers while the tile's digits are counted, then takes its slot in
+            // the sorted order from its digit's LDS cursor and goes through the stage, digits [0, s) first and [s, R) second
+            // (s = the digit that holds sorted slot SK1_STAGE: both halves fit unless that one digit has more than 128
+            // records in this tile -- skew, the gather below), and leaves in runs -- 16 bytes per lane, consecutive lanes to
+            // consecutive addresses.  No sorted position is ever kept in a register (round 3 kept eight, and spilled 23
+            // VGPRs around the scan: 96 bytes of scratch per lane and tile).  (Reading the digits first and gathering the
+            // records by index afterwards -- the partial tile's way below -- brings every record in twice: 16 GB moved for 10.7.)
             ull2_t rec[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++)
                 rec[j] = src[t0 + tid + j * SK1_NT];
-            u32 pos[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const bool null = (rec[j].y >> 63) != 0;
                 const u32 dg = null ? R : (u32)(rec[j].y >> shift) & dmask;
-                pos[j] = atomicAdd(&cnt[dg], 1u);
+                atomicAdd(&cnt[dg], 1u);
                 if (SPEC && !null)
                     atomicAdd(&kcs[dg], (u32)((rec[j].y >> 44) & 31) + 1u);
             }
             __syncthreads();
-            block_scan_inplace<SK1_NT>(cnt, (int)R + 1, wtmp);             // cnt -> exclusive offsets; cnt[R] = the tile's records
-            u32 got = 0;
-            const bool reserve = gc && (u32)tid < R;
-            if (reserve) {
-                const u32 c = cnt[tid + 1] - cnt[tid];
-                if (c)
-                    got = atomicAdd(&gc[tid], c);
-                if (SPEC && c && (u64)got + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
-                    dropped = true;
-            }
+            block_scan_small<SK1_NT>(cnt, (int)R + 1, wtmp, tid);      // (R + 1 <= 513)             // cnt -> exclusive offsets; cnt[R] = the tile's records
             const u32 n_valid = cnt[R];
+            if ((u32)tid < R && cnt[tid] <= (u32)SK1_STAGE && cnt[tid + 1] > (u32)SK1_STAGE) {
+                split[0] = (u32)tid;               // (exactly one digit holds slot SK1_STAGE, if the tile has that many)
+                split[1] = cnt[tid];
+                split[2] = n_valid - cnt[tid] > (u32)SK1_STAGE ? 1u : 0u;
+            }
+            place_digits();
+            placed = true;
+            __syncthreads();                       // (the offsets have been read: the cursors below move them)
+            const u32 s_dig = split[0];
+            gather = split[2] != 0;
+            if (!gather) {
+                const u32 s_off = s_dig < R ? split[1] : n_valid;
 #pragma unroll
-            for (int j = 0; j < SK1_ITEMS; j++)
-                pos[j] = (rec[j].y >> 63) ? ~0u : pos[j] + cnt[(u32)(rec[j].y >> shift) & dmask];
+                for (int h = 0; h < 2; h++) {
+                    const u32 lo = h ? s_off : 0u, hi = h ? n_valid : s_off;   // sorted slots of this half
+                    if (lo == hi)
+                        continue;                  // (wave-uniform, workgroup-uniform)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+                    for (int j = 0; j < SK1_ITEMS; j++) {
+                        const u32 dg = (u32)(rec[j].y >> shift) & dmask;
+                        if (!(rec[j].y >> 63) && (dg >= s_dig) == (h != 0))
+                            stage[atomicAdd(&cnt[dg], 1u) - lo] = rec[j];
+                    }
+                    __syncthreads();
 #pragma unroll
-                for (int j = 0; j < SK1_ITEMS; j++)
-                    if ((pos[j] >> 12) == (u32)h)
-                        stage[pos[j] & 4095u] = rec[j];
-                if (h == 0 && reserve)
-                    gpos[tid] = got;
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < SK1_ITEMS / 2; j++) {
-                    const u32 sl = (u32)h * (SK1_TILE / 2) + tid + j * SK1_NT;
-                    if (sl >= n_valid)
-                        continue;
-                    const ull2_t r = stage[tid + j * SK1_NT];
-                    const u32 d = (u32)(r.y >> shift) & dmask;
-                    // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
-                    // this workgroup's next tile -- completes them; kept in L2 they merge more often: 3.44 -> 3.30 ms)
-                    const u32 p = gpos[d] + (sl - cnt[d]);
-                    if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
-                        dst_all[p] = r;
+                    for (int j = 0; j < (SK1_STAGE + SK1_NT - 1) / SK1_NT; j++) {
+                        const u32 sl = lo + (u32)tid + (u32)j * SK1_NT;
+                        if (sl >= hi)
+                            continue;
+                        const ull2_t r = stage[sl - lo];
+                        const u32 d = (u32)(r.y >> shift) & dmask;
+                        // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
+                        // this workgroup's next tile -- completes them; kept in L2 they merge more often: 3.44 -> 3.30 ms)
+                        const u32 p = gadj[d] + sl;
+                        if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
+                            dst_all[p] = r;
+                    }
+                    __syncthreads();
                 }
+            } else {
+                for (u32 d = tid; d <= R; d += SK1_NT)
+                    cnt[d] = 0;                    // (the gather ranks the tile again; its slots are reserved already)
                 __syncthreads();
             }
-        } else {
+        }
+        if (gather) {
             u32 dig[SK1_ITEMS], rank[SK1_ITEMS];
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
@@ -858,21 +898,14 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const bool null = (m >> 63) != 0;
                     dig[j] = null ? R : (u32)(m >> shift) & dmask;
                     rank[j] = atomicAdd(&cnt[dig[j]], 1u);
-                    if (SPEC && !null)
+                    if (SPEC && !null && !placed)
                         atomicAdd(&kcs[dig[j]], (u32)((m >> 44) & 31) + 1u);
                 }
             }
             __syncthreads();
-            block_scan_inplace<SK1_NT>(cnt, (int)R + 1, wtmp);             // cnt -> exclusive offsets; cnt[R] = the tile's records
-            if (gc && (u32)tid < R) {
-                const u32 c = cnt[tid + 1] - cnt[tid];
-                if (c) {
-                    const u32 got = atomicAdd(&gc[tid], c);
-                    gpos[tid] = got;
-                    if (SPEC && (u64)got + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
-                        dropped = true;
-                }
-            }
+            block_scan_small<SK1_NT>(cnt, (int)R + 1, wtmp, tid);      // (R + 1 <= 513)             // cnt -> exclusive offsets; cnt[R] = the tile's records
+            if (!placed)
+                place_digits();
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const u32 i = tid + j * SK1_NT;
@@ -886,17 +919,11 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                 if (sl < cnt[R]) {
                     const ull2_t r = src[t0 + idx[sl]];
                     const u32 d = (u32)(r.y >> shift) & dmask;
-                    const u32 p = gpos[d] + (sl - cnt[d]);
+                    const u32 p = gadj[d] + sl;
                     if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
                         __builtin_nontemporal_store(r, &dst_all[p]);
                 }
             }
-            __syncthreads();
-        }
-        // advance: digit d held (next offset - its offset) records
-        if (!gc) {
-            for (u32 d = tid; d < R; d += SK1_NT)
-                gpos[d] += cnt[d + 1] - cnt[d];
             __syncthreads();
         }
     }
@@ -1215,6 +1242,11 @@ hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const 
 constexpr int SKR_NT = 1024;
 constexpr int SKR_ITEMS = 8;
 constexpr int SKR_TILE = SKR_NT * SKR_ITEMS;
+// LONG = false: the mid buckets of at most one tile (all of them on random sequence; the others are left alone);
+// LONG = true: the longer ones only (launched when the host has seen one: the records per mid bucket are on the host).
+// Two kernels, so that the common one carries neither the long path's code nor its registers (as one kernel it showed
+// 76 bytes of scratch per lane: the records' registers spilled around the long path's loop).
+template <bool LONG>
 __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__restrict__ mids, u32 n_mids,
                                                             const ull2_t *__restrict__ src_all, ull2_t *__restrict__ dst_all,
                                                             Node *__restrict__ out_nodes)
@@ -1229,6 +1261,8 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
         return;
     const int tid = threadIdx.x, lane = tid & 63;
     const Node nd = mids[i];
+    if ((nd.len > (u32)SKR_TILE) != LONG)
+        return;
     const ull2_t *src = src_all + (u64)nd.start;
     for (int q = tid; q < 64 * 17; q += SKR_NT) {
         (&rc[0][0])[q] = 0;
@@ -1240,14 +1274,15 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
     __syncthreads();
     // A mid bucket of at most one tile (the planned size is ~5,000 records): its digit words are read ONCE -- counted
     // for the output nodes and ranked for the copy in the same sweep.
-    const bool one_tile = nd.len <= (u32)SKR_TILE;
+    constexpr bool one_tile = !LONG;
     const u32 last = nd.len ? nd.len - 1u : 0u;
     // A bucket of one tile reads every record ONCE, 16 bytes per lane, all of a thread's loads in flight (no bounds test:
     // a slot past the end reads the last record again and drops it); the records wait in registers while they are counted
     // and ranked, and leave through LDS in regrouped order (as sk_scatter1's full tiles do).
-    ull2_t rec[SKR_ITEMS];
-    u32 pos[SKR_ITEMS];
-    if (one_tile && nd.len) {
+    ull2_t rec[LONG ? 1 : SKR_ITEMS];
+    u32 pos[LONG ? 1 : SKR_ITEMS];
+    if constexpr (one_tile) {
+      if (nd.len) {
 #pragma unroll
         for (int j = 0; j < SKR_ITEMS; j++) {
             const u32 r = tid + j * SKR_NT;
@@ -1267,7 +1302,8 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
                 pos[j] = atomicAdd(&tcnt[d2], 1u);
             }
         }
-    } else if (!one_tile) {
+      }
+    } else {
         for (u32 r = tid; r < nd.len; r += SKR_NT) {
             const u64 m = reinterpret_cast<const u64 *>(src + r)[1];
             const u32 d2 = (u32)(m >> 59) & 15u;
@@ -1291,28 +1327,27 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
             qc[0][tid & 15] = sum;
     }
     __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (int j = 0; j < 16; j++) {
-            gpos[j] = nd.start + run;
-            Node o;
-            o.start = nd.start + run;
-            o.len = rc[0][j];
-            o.meta = 0;
-            o.split = 0;
-            o.prefix = 0;
-            o.child_base = kc[0][j];
-            o.chunk_base = qc[0][j];
-            out_nodes[(u64)i * 16 + j] = o;
-            if (one_tile)
-                tcnt[j] = run;                     // the tile's digit offsets (its counts are the bucket's)
-            run += rc[0][j];
+    if (tid < 16) {                                // (a thread per final bucket: thread 0 alone held sixteen nodes' worth of
+        const u32 c = rc[0][tid];                  // registers while every thread's records waited -- 18 of them spilled)
+        const u32 run = row16_excl_scan(c);
+        gpos[tid] = nd.start + run;
+        Node o;
+        o.start = nd.start + run;
+        o.len = c;
+        o.meta = 0;
+        o.split = 0;
+        o.prefix = 0;
+        o.child_base = kc[0][tid];
+        o.chunk_base = qc[0][tid];
+        out_nodes[(u64)i * 16 + tid] = o;
+        if (one_tile) {
+            tcnt[tid] = run;                       // the tile's digit offsets (its counts are the bucket's)
+            if (tid == 15)
+                tcnt[16] = run + c;
         }
-        if (one_tile)
-            tcnt[16] = run;
     }
     __syncthreads();
-    if (one_tile) {
+    if constexpr (one_tile) {
         if (nd.len == 0)
             return;
 #pragma unroll
@@ -1332,11 +1367,8 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
 #pragma unroll
             for (int j = 0; j < SKR_ITEMS / 2; j++) {
                 const u32 s2 = (u32)h * (SKR_TILE / 2) + tid + j * SKR_NT;
-                if (s2 < nd.len) {
-                    const ull2_t r = stage[tid + j * SKR_NT];
-                    const u32 d = (u32)(r.y >> 59) & 15u;
-                    __builtin_nontemporal_store(r, &dst_all[gpos[d] + (s2 - tcnt[d])]);
-                }
+                if (s2 < nd.len)                   // (the final buckets lie back to back in the mid bucket's own range)
+                    __builtin_nontemporal_store(stage[tid + j * SKR_NT], &dst_all[nd.start + s2]);
             }
             __syncthreads();
         }
@@ -1397,12 +1429,17 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
     }
 }
 
-hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, hipStream_t s)
+int sk_regroup_tile() { return SKR_TILE; }
+
+hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void *dst, Node *out_nodes, bool any_long, hipStream_t s)
 {
     if (n_mids == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_regroup_kernel, dim3(n_mids), dim3(SKR_NT), 0, s, mids, n_mids, reinterpret_cast<const ull2_t *>(src),
+    hipLaunchKernelGGL(sk_regroup_kernel<false>, dim3(n_mids), dim3(SKR_NT), 0, s, mids, n_mids, reinterpret_cast<const ull2_t *>(src),
                        reinterpret_cast<ull2_t *>(dst), out_nodes);
+    if (any_long)
+        hipLaunchKernelGGL(sk_regroup_kernel<true>, dim3(n_mids), dim3(SKR_NT), 0, s, mids, n_mids, reinterpret_cast<const ull2_t *>(src),
+                           reinterpret_cast<ull2_t *>(dst), out_nodes);
     return hipGetLastError();
 }
 
