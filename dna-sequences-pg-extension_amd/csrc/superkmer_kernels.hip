@@ -71,26 +71,31 @@ __device__ __forceinline__ u32 sk_mix(u32 h)
     return h;
 }
 
-// the three bucket digits of a minimizer hash.  The minimum of w hashes is small, i.e. its high bits are biased: the
-// digits are cut from a product of 24 LOW bits of the hash (unbiased) with an odd constant -- v_mul_u32_u24 is a
-// full-rate instruction, the 32-bit multiply this replaces a quarter-rate one.  d2 and d1 come from product bits 2..15
-// (functions of the hash's low 16 bits), d0 from bits 16..31 scaled to [0, c0) by a second 24-bit multiply.
+// The three bucket digits of a k-mer, functions of its minimum m-mer (so equal k-mers share them).
+//   d0 (coarse, < c0 <= 256) comes from the m-mer's HASH as the window minima carry it (hmin = hash bits 7..31 | 64 |
+//   position): the level-0 histogram needs it for every row, and the hash is what a row has.  The minimum of w hashes is
+//   small -- its high bits are biased, ~21 bits of it vary -- which is plenty for 256 coarse buckets and far too little for
+//   the ~10^6 final ones (tried: final buckets of ~5 hash classes each, a third of them over sk_count's stage).
+//   d1 (< 2^b1) and d2 (< 16) therefore come from the m-mer's 30-bit VALUE, which a record's builder cuts from the tile's
+//   words at the minimum's position (once per record, not per row).
+// v_mul_u32_u24 is a full-rate instruction; the 32-bit multiply of sk_fine_word runs once per record.
 struct SkDigits {
     u32 d0, d1, d2;
 };
-// (hmin = a window minimum as sk_front makes it: hash bits 7..31, bit 6 set, the minimum's position in bits 0..5 -- the
-// digits are cut from hash bits 7..30)
 __device__ __forceinline__ u32 sk_digit_word(u32 hmin) { return __umul24(hmin >> 7, 0x9E3779u); }
 __device__ __forceinline__ u32 sk_digit0(u32 g, u32 c0) { return __umul24(g >> 16, c0) >> 16; }
-__device__ __forceinline__ SkDigits sk_digits(u32 hmin, u32 c0, u32 b1mask)
+__device__ __forceinline__ u32 sk_fine_word(u32 v) { return v * 0x9E3779B1u; }
+__device__ __forceinline__ SkDigits sk_digits(u32 hmin, u32 v, u32 c0, u32 b1mask)
 {
-    const u32 g = sk_digit_word(hmin);
+    const u32 f = sk_fine_word(v);
     SkDigits r;
-    r.d0 = sk_digit0(g, c0);
-    r.d1 = (g >> 6) & b1mask;
-    r.d2 = (g >> 2) & 15u;
+    r.d0 = sk_digit0(sk_digit_word(hmin), c0);
+    r.d1 = (f >> 23) & b1mask;
+    r.d2 = (f >> 19) & 15u;
     return r;
 }
+// the window minimum an m-mer of value v makes (its position bits clear): what sk_front computes for it
+__device__ __forceinline__ u32 sk_hash_of(u32 v) { return (sk_mix(v) & ~SK_GPOS_MASK) | 64u; }
 
 // timing ablations (results invalid) exist in the diagnostic build (make STAMPS=1) only
 #ifdef DNAGPU_STAMPS
@@ -243,8 +248,8 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     // minima, hash AND position (cut at the tile's end): one m-mer occurrence stays the minimum of at most W <= 18
     // windows, so such a record never outgrows lmax, and all its k-mers have their leftmost minimum m-mer at one place.
     // On random sequence every tile is plain.  Longer runs of one hash need a repeated m-mer (low-complexity sequence):
-    // there the position moves on row after row, and the tile goes through the general walk, which cuts by hash alone
-    // every lmax rows (SK_REC_MULTI records).  Test on every fourth row of the tile: six such samples in a row span 21
+    // there the position moves on row after row, and the tile goes through the general walk, which cuts by the minimum
+    // m-mer's VALUE and every lmax rows (SK_REC_MULTI records).  Test on every fourth row of the tile: six such samples in a row span 21
     // rows -- more than any run of W rows covers -- so six equal samples in a row send the tile through the general
     // walk, and nothing else does.  (Shorter stretches of a repeated m-mer stay in plain tiles as a few short records.)
     u32 smp[13];
@@ -263,20 +268,74 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     f.plain = n_rows == (u32)SKW_ROWS && __ballot(long_run && lane < 63) == 0;
 }
 
-// what the general walk (sk_records / sk_records_all) and the start rows of a plain tile's records need of the lanes
-// before this one: the last natural break (a row whose minimum differs from the row before; the tile's first row counts)
-// among the lanes' rows -> ns0 = the start row of the natural run that reaches this lane's first row from the left, and
-// c0 = the length so far of the RECORD open there (records are cut every lmax rows of a run)
-// two minima belong to different runs: by hash alone (BYG: the general walk of a non-plain tile), or by hash and position
-// (a plain tile whose list overflowed: the same records as its branch-free walk)
-template <bool BYG>
-__device__ __forceinline__ bool sk_differ(u32 x, u32 y)
+// bits [sh, sh + 64) of hi:lo, sh in 0 .. 127
+__device__ __forceinline__ u64 sk_shr128(u64 lo, u64 hi, u32 sh)
 {
-    return BYG ? (x ^ y) > SK_GPOS_MASK : x != y;
+    return sh < 64u ? funnel(lo, hi, sh) : hi >> (sh - 64u);
 }
 
-template <bool BYG, int W>
-__device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
+// ---- the general walk (a partial tile, low-complexity sequence, a plain tile whose list overflowed).  Runs are cut where a
+// row's RUN KEY differs from the row before; a record is a run, cut every lmax rows and at the tile's end.
+//   exact keys (a plain tile whose list overflowed, a partial tile of plain sequence): the minima themselves, hash and
+//     position -- the same records as the branch-free walk of a plain tile;
+//   value keys (SkValueKeys: everything else): the VALUE of the row's minimum m-mer.  Where one m-mer repeats (poly-A,
+//     tandem repeats) the minimum's position moves on row after row while its value stays: runs by value keep such
+//     stretches in records of lmax k-mers instead of one record per row.  All k-mers of such a record still share the
+//     m-mer's value -- and so all three bucket digits -- but not its place: SK_REC_MULTI.
+// The keys are computed row by row as the walk goes (a value key is a 128-bit funnel shift of the lane's bases: kept as
+// an array, the 32 of them cost sk_scatter0 65 spilled registers).
+template <int W, bool BATCH, bool BYV>
+struct SkKeys {
+    const SkFront<W> &f;
+    u64 lo, hi;                    // BYV: the lane's 64 bases from its first row on
+    u32 mmask;
+    u32 next_first, prev_last;     // the neighbouring lanes' boundary keys, comparable with this lane's
+
+    __device__ __forceinline__ SkKeys(const SkFront<W> &f_, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 mmask_)
+        : f(f_), lo(0), hi(0), mmask(mmask_)
+    {
+        if (BYV) {
+            // (what sk_front cut its m-mers from, read again: this is the rare path)
+            const u64 pos = pos0 + (u64)(threadIdx.x & 63) * 32;
+            const u64 w = pos >> 5;
+            const unsigned sh = (unsigned)(pos & 31) * 2;
+            const u64 w0 = w < n_words ? words[w] : 0, w1 = w + 1 < n_words ? words[w + 1] : 0;
+            lo = w0;
+            hi = w1;
+            if (sh) {
+                const u64 w2 = w + 2 < n_words ? words[w + 2] : 0;
+                lo = (w0 >> sh) | (w1 << (64 - sh));
+                hi = (w1 >> sh) | (w2 << (64 - sh));
+            }
+            next_first = wave_next((*this)(0));
+            prev_last = wave_prev((*this)(31));
+        } else {
+            next_first = f.next_first;
+            prev_last = f.prev_last;
+        }
+    }
+    // (between two sweeps over the rows: the value keys are computed again, not kept -- 32 live keys spill)
+    __device__ __forceinline__ void forget()
+    {
+        if (BYV)
+            asm volatile("" : "+v"(lo), "+v"(hi));
+    }
+    __device__ __forceinline__ u32 operator()(int j) const
+    {
+        if (!BYV)
+            return f.hm[j];
+        if (BATCH && f.hm[j] < 64u)
+            return ~0u;                            // (a row across a sequence start: no m-mer value is all ones)
+        const u32 p = f.hm[j] & SK_GPOS_MASK;     // (<= 31 + W - 1 <= 48: the m-mer lies inside the lane's 64 bases)
+        return (u32)sk_shr128(lo, hi, 2u * p) & mmask;
+    }
+};
+
+// what the walk needs of the lanes before this one: the last break (a row whose key differs from the row before; the
+// tile's first row counts) among the lanes' rows -> ns0 = the start row of the run that reaches this lane's first row from
+// the left, and c0 = the length so far of the RECORD open there (records are cut every lmax rows of a run)
+template <int W, typename Keys>
+__device__ __forceinline__ void sk_front_open(SkFront<W> &f, const Keys &key, u32 lmax)
 {
     const int lane = threadIdx.x & 63;
     // (opaque to the compiler: else the 32 row numbers r0 + j -- and, where they are widened, their 64-bit forms -- are
@@ -285,69 +344,96 @@ __device__ __forceinline__ void sk_front_open(SkFront<W> &f, u32 lmax)
     u32 r0 = (u32)lane * 32;
     asm volatile("" : "+v"(r0));
     u32 lb = 0;
-#pragma unroll
+    u32 kprev = key.prev_last;
+    const u32 k0 = key(0);
+    u32 kcur = k0;
+#pragma unroll 1
     for (int j = 0; j < 32; j++) {
-        // (BYG compares hashes: prev_last + 32 is the lane before's minimum as it stood)
-        const bool brk = j == 0 ? (lane == 0 || sk_differ<BYG>(f.hm[0], BYG ? f.prev_last + 32u : f.prev_last))
-                                : sk_differ<BYG>(f.hm[j], f.hm[j - 1]);
+        const bool brk = j == 0 ? (lane == 0 || kcur != kprev) : kcur != kprev;
         if (brk)
             lb = r0 + (u32)j + 1u;
+        kprev = kcur;
+        if (j < 31)
+            kcur = key(j + 1);
     }
     const u32 before = wave_prev(wave_incl_max(lb));       // over the lanes before this one (lane 0: 0)
     // `before` >= 1 for every lane but lane 0 (row 0 is a break); lane 0's own row 0 is a break too
     f.ns0 = before ? before - 1u : 0u;
-    const bool first_break = lane == 0 || sk_differ<BYG>(f.hm[0], BYG ? f.prev_last + 32u : f.prev_last);
+    const bool first_break = lane == 0 || k0 != key.prev_last;
     f.c0 = first_break ? 0u : (r0 - f.ns0) % lmax;
     if (first_break)
         f.ns0 = r0;
 }
 
-// the same walk with the callback at EVERY row position (end = a record ends at this thread's row j; false for rows
-// that do not exist), so that the callback may use wave-wide operations
-template <bool BYG, int W, typename Emit>
-__device__ __forceinline__ void sk_records_all(const SkFront<W> &f, u32 lmax, Emit &&emit)
+// the walk with the callback at EVERY row position (end = a record ends at this thread's row j; false for rows
+// that do not exist), so that the callback may use wave-wide operations: emit(j, end, row, len, hmin, key)
+template <int W, typename Keys, typename Emit>
+__device__ __forceinline__ void sk_records_all(const SkFront<W> &f, const Keys &key, u32 lmax, Emit &&emit)
 {
     u32 r0 = (u32)(threadIdx.x & 63) * 32;
     asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
-#pragma unroll
+    u32 kprev = 0, kcur = key(0);
+#pragma unroll 1
     for (int j = 0; j < 32; j++) {
+        const u32 nxt = j < 31 ? key(j + 1) : key.next_first;
         bool end = false;
         if ((u32)j < f.n_valid) {
-            if (j > 0 && sk_differ<BYG>(f.hm[j], f.hm[j - 1]))
+            if (j > 0 && kcur != kprev)
                 c = 0;
-            const u32 nxt = j < 31 ? f.hm[j + 1] : f.next_first;
-            end = r0 + (u32)j + 1 == f.n_rows || sk_differ<BYG>(nxt, f.hm[j]) || c + 1 == lmax;
+            end = r0 + (u32)j + 1 == f.n_rows || nxt != kcur || c + 1 == lmax;
         }
-        emit(j, end, r0 + (u32)j, c + 1, f.hm[j]);
+        emit(j, end, r0 + (u32)j, c + 1, f.hm[j], kcur);
         c = end ? 0u : c + 1;
+        kprev = kcur;
+        kcur = nxt;
     }
 }
 
-// walks the thread's rows in order and calls emit(j, end_row, len, hmin) for every record that ENDS in them (j = the
-// row's index among the thread's 32: a constant once the loop is unrolled)
-template <bool BYG, int W, typename Emit>
-__device__ __forceinline__ void sk_records(const SkFront<W> &f, u32 lmax, Emit &&emit)
+// walks the thread's rows in order and calls emit(j, end_row, len, hmin, key) for every record that ENDS in them (j = the
+// row's index among the thread's 32).  (These walks run out of line -- sk_hist0_general, sk_scatter0_general -- with the
+// SkFront in memory: their loops over the rows stay rolled, a dozen registers instead of a hundred.)
+template <int W, typename Keys, typename Emit>
+__device__ __forceinline__ void sk_records(const SkFront<W> &f, const Keys &key, u32 lmax, Emit &&emit)
 {
     u32 r0 = (u32)(threadIdx.x & 63) * 32;
     asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
-#pragma unroll
+    u32 kprev = 0, kcur = key(0);
+#pragma unroll 1
     for (int j = 0; j < 32; j++) {
+        const u32 nxt = j < 31 ? key(j + 1) : key.next_first;
         if ((u32)j < f.n_valid) {
-            if (j > 0 && sk_differ<BYG>(f.hm[j], f.hm[j - 1]))
+            if (j > 0 && kcur != kprev)
                 c = 0;                                     // (a break at j == 0 is already in c0)
-            const u32 nxt = j < 31 ? f.hm[j + 1] : f.next_first;
             const bool last = r0 + (u32)j + 1 == f.n_rows;   // records are cut at the tile's end
-            const bool end = last || sk_differ<BYG>(nxt, f.hm[j]) || c + 1 == lmax;
+            const bool end = last || nxt != kcur || c + 1 == lmax;
             if (end) {
-                emit(j, r0 + (u32)j, c + 1, f.hm[j]);
+                emit(j, r0 + (u32)j, c + 1, f.hm[j], kcur);
                 c = 0;
             } else {
                 c++;
             }
         }
+        kprev = kcur;
+        kcur = nxt;
     }
+}
+
+// The general walk of sk_hist0, OUT OF LINE: non-plain tiles are rare (none on random sequence), and inlined the walk's
+// registers were the kernel's (85 -> 128 VGPRs with spills: one wave less per SIMD for every tile).
+template <int W, bool BATCH>
+__device__ __noinline__ void sk_hist0_general(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 lmax, u32 mmask,
+                                              u32 c0n, u32 *h /* LDS */)
+{
+    SkKeys<W, BATCH, true> vk(f, words, n_words, pos0, mmask);
+    sk_front_open<W>(f, vk, lmax);
+    vk.forget();
+    if ((threadIdx.x & 63) < 63)
+        sk_records<W>(f, vk, lmax, [&](int, u32, u32, u32 hmin, u32 v) {
+            if (!BATCH || v != ~0u)
+                atomicAdd(&h[sk_digit0(sk_digit_word(hmin), c0n)], 1u);
+        });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,12 +474,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
                 }
             }
         } else {
-            sk_front_open<true, W>(f, lmax);
-            if (lane < 63)
-                sk_records<true, W>(f, lmax, [&](int, u32, u32, u32 hmin) {
-                    if (!BATCH || (hmin >> 6) != 0u)
-                        atomicAdd(&h[sk_digits(hmin, c0n, b1mask).d0], 1u);
-                });
+            sk_hist0_general<W, BATCH>(f, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
         }
     }
     __syncthreads();
@@ -406,6 +487,131 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
     u32 *row = hist + (u64)blockIdx.x * ROW_STRIDE;
     for (u32 d = threadIdx.x; d < r0n; d += SK_NT)
         row[d] = h[d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// What building a tile's records needs of its kernel (sk_scatter0): the wave's LDS list / words / start table, the
+// chunk's cursors, the record buffer.
+struct SkBuild {
+    u64 *wl;                // list entries: key << 32 | start row << 16 | end row; start = 0xFFFF: the run started in an
+                            // earlier lane (ns_tab)
+    const u64 *wsh;         // the tile's packed words (word 0 = the one holding its first base)
+    const u32 *ns_tab;      // per lane: start row of the run that is open at the lane's first row
+    u32 *gpos;              // per coarse digit: the chunk's next slot
+    const u32 *gend;        // ... and the end of its slots (slab mode; else all ones)
+    ull2_t *recs;
+    u32 fo, c0n, b1mask, mmask;
+    int k, dbg;
+};
+
+// Every lane builds and stores the records of its share of the list.  exact: the listed records are runs of one minimum,
+// hash and position (key = that minimum) -- they carry the minimum m-mer's offset, and the m-mer's value (for d1 / d2) is
+// cut from the tile's words there; else (the walk by the m-mer's value: key = that value) SK_REC_MULTI.  Returns true if
+// a record found its digit's slots used up (slab mode).
+template <bool BATCH>
+__device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, bool exact)
+{
+    const int dbg = b.dbg;
+    (void)dbg;
+    bool dropped = false;
+    if (SK_DBG(2))
+        return false;
+    for (u32 e = threadIdx.x & 63u; e < wrun; e += 64) {
+        const u64 en = b.wl[e];
+        const u32 key = (u32)(en >> 32);
+        if (BATCH && (exact ? key < 64u : key == ~0u))
+            continue;                              // (a run of rows across a sequence start: not rows of the table)
+        const u32 end_row = (u32)en & 0xFFFFu;
+        u32 v = key, hmin = key;
+        if (exact) {                               // the minimum's position counts from the first row of the lane of end_row
+            const u32 xq = (end_row & ~31u) + (key & SK_GPOS_MASK) + b.fo;
+            v = (u32)funnel(b.wsh[xq >> 5], b.wsh[(xq >> 5) + 1], (xq & 31u) * 2u) & b.mmask;
+        } else {
+            hmin = sk_hash_of(v);
+        }
+        const SkDigits dg = sk_digits(hmin, v, b.c0n, b.b1mask);
+        const u32 gslot = atomicAdd(&b.gpos[dg.d0], 1u);
+        u32 start = ((u32)en >> 16) & 0xFFFFu;
+        start = start == 0xFFFFu ? b.ns_tab[end_row >> 5] : start;
+        const u32 len = end_row - start + 1u;
+        // the record's 108 payload bits from bit 2 q of the tile's words: six dwords, four funnel shifts
+        const u32 q = start + b.fo;                // first base of the run, relative to the tile's first word
+        const u32 wi = q >> 5, sh = (q & 15u) * 2u;
+        const u64 a0 = b.wsh[wi], a1 = b.wsh[wi + 1], a2 = b.wsh[wi + 2];
+        const bool odd = (q & 16u) != 0;
+        const u32 e0 = odd ? (u32)(a0 >> 32) : (u32)a0, e1 = odd ? (u32)a1 : (u32)(a0 >> 32),
+                  e2 = odd ? (u32)(a1 >> 32) : (u32)a1, e3 = odd ? (u32)a2 : (u32)(a1 >> 32),
+                  e4 = odd ? (u32)(a2 >> 32) : (u32)a2;
+        u64 lo = ((u64)__builtin_amdgcn_alignbit(e2, e1, sh) << 32) | __builtin_amdgcn_alignbit(e1, e0, sh);
+        u64 hi = ((u64)__builtin_amdgcn_alignbit(e4, e3, sh) << 32) | __builtin_amdgcn_alignbit(e3, e2, sh);
+        const u32 nb = len + (u32)b.k - 1;
+        if (nb < 32) {
+            lo &= ((u64)1 << (2 * nb)) - 1;
+            hi = 0;
+        } else {
+            hi &= ((u64)1 << (2 * (nb - 32))) - 1;
+        }
+        const u32 mpos = (end_row & ~31u) + (key & SK_GPOS_MASK) - start;
+        const u32 tag = exact ? (mpos & SK_POS_MASK) << (SK_POS_SHIFT - 32) : 1u << (SK_REC_MULTI_BIT - 32);
+        hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59) | ((u64)tag << 32);
+        ull2_t r;
+        r.x = lo;
+        r.y = hi;
+        if (gslot >= b.gend[dg.d0])
+            dropped = true;                        // (slab mode: the chunk's slots of this digit are used up)
+        else if (!SK_DBG(1))
+            b.recs[gslot] = r;
+        else if (r.x == 0x1234567 && r.y == 0x89)
+            b.recs[0] = r;
+    }
+    return dropped;
+}
+
+// The general walk of sk_scatter0, OUT OF LINE (see sk_hist0_general): a partial tile or long runs of one hash (by_value:
+// records = runs of one m-mer VALUE, cut every lmax rows), or a plain tile whose list overflowed (!by_value: the SAME records
+// as its branch-free walk -- sk_hist0 counted those -- in four passes of eight row positions each, which always fit).
+template <int W, bool BATCH, bool BYV>
+__device__ __forceinline__ bool sk_scatter0_walk(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
+                                                 u64 tile_pos, u32 lmax)
+{
+    const u64 below = ((u64)1 << (threadIdx.x & 63)) - 1;
+    u64 *wl = bx.wl;
+    bool dropped = false;
+    SkKeys<W, BATCH, BYV> key(f, words, n_words, tile_pos, bx.mmask);
+    sk_front_open<W>(f, key, lmax);
+    for (int n_pass = BYV ? 1 : 4, pass = 0; pass < n_pass; pass++) {
+        const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
+        u32 wrun = 0;
+        key.forget();
+        sk_records_all<W>(f, key, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32, u32 kj) {
+            const bool end = end_any && j >= jlo && j < jhi;
+            const u64 b = __ballot(end);
+            if (end) {
+                const u32 pos = wrun + (u32)__popcll(b & below);
+                if (pos < (u32)SKW_LIST)
+                    wl[pos] = ((u64)kj << 32) | ((u64)(end_row + 1 - len) << 16) | (u64)end_row;
+            }
+            wrun += (u32)__popcll(b);
+        });
+        if (wrun > (u32)SKW_LIST) {                // (only possible in a single pass)
+            n_pass = 4;
+            pass = -1;
+            sk_wave_fence();
+            continue;
+        }
+        sk_wave_fence();                           // list and words written by other lanes of this wave
+        if (sk_build<BATCH>(bx, wrun, !BYV))
+            dropped = true;
+        sk_wave_fence();                           // wsh / list are rewritten by the next pass / tile
+    }
+    return dropped;
+}
+template <int W, bool BATCH>
+__device__ __noinline__ bool sk_scatter0_general(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
+                                                 u64 tile_pos, u32 lmax, bool by_value)
+{
+    return by_value ? sk_scatter0_walk<W, BATCH, true>(f, bx, words, n_words, tile_pos, lmax)
+                    : sk_scatter0_walk<W, BATCH, false>(f, bx, words, n_words, tile_pos, lmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -455,8 +661,20 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
     __syncthreads();
     u64 *wsh = wsh_all[wave], *wl = list_all[wave];
     u32 *ns_tab = ns_all[wave];
-    const u64 below = ((u64)1 << lane) - 1;
     bool dropped = false;
+    SkBuild bx;
+    bx.wl = wl;
+    bx.wsh = wsh;
+    bx.ns_tab = ns_tab;
+    bx.gpos = gpos;
+    bx.gend = gend;
+    bx.recs = recs;
+    bx.fo = 0;
+    bx.c0n = c0n;
+    bx.b1mask = b1mask;
+    bx.mmask = mmask;
+    bx.k = k;
+    bx.dbg = dbg;
     for (u32 t0 = (u32)wave * SKW_ROWS; t0 < ch.len; t0 += SK_TILE_ROWS) {
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         const u64 tile_pos = first + ch.off + t0;
@@ -464,56 +682,14 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         SkFront<W> f;
         sk_front<W, BATCH>(f, words, n_words, tile_pos, n_rows, lmax, mmask, wsh, marks, n_mark_words);
         // The records that end in this tile (usually ~225) are listed in the wave's LDS list (ballot + prefix count per
-        // row position: no atomics), and every lane then builds the payloads of its share -- building them where they end
-        // would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the list
-        // (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
+        // row position: no atomics), and every lane then builds the payloads of its share (sk_build) -- building them where
+        // they end would run the payload code for all 32 row positions, ~9 times the work.  A tile that would overflow the
+        // list (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
         // fit (8 x 63 records).
-        // list entry: hmin << 32 | start row << 16 | end row; start = 0xFFFF: the run started in an earlier lane (ns_tab)
-        // exact: the listed records are runs of one minimum, hash and position (a plain tile) -- they carry the minimum
-        // m-mer's offset; else (the general walk by hash alone) SK_REC_MULTI
-        auto build = [&](u32 wrun, bool exact) {  // every lane builds and stores the records of its share of the list
-            if (!SK_DBG(2))
-                for (u32 e = (u32)lane; e < wrun; e += 64) {
-                    const u64 en = wl[e];
-                    if (BATCH && (en >> 38) == 0)
-                        continue;                  // (a run of rows across a sequence start: not rows of the table)
-                    const SkDigits dg = sk_digits((u32)(en >> 32), c0n, b1mask);
-                    const u32 gslot = atomicAdd(&gpos[dg.d0], 1u);
-                    const u32 end_row = (u32)en & 0xFFFFu;
-                    u32 start = ((u32)en >> 16) & 0xFFFFu;
-                    start = start == 0xFFFFu ? ns_tab[end_row >> 5] : start;
-                    const u32 len = end_row - start + 1u;
-                    // the record's 108 payload bits from bit 2 q of the tile's words: six dwords, four funnel shifts
-                    const u32 q = start + fo;      // first base of the run, relative to the tile's first word
-                    const u32 wi = q >> 5, sh = (q & 15u) * 2u;
-                    const u64 a0 = wsh[wi], a1 = wsh[wi + 1], a2 = wsh[wi + 2];
-                    const bool odd = (q & 16u) != 0;
-                    const u32 e0 = odd ? (u32)(a0 >> 32) : (u32)a0, e1 = odd ? (u32)a1 : (u32)(a0 >> 32),
-                              e2 = odd ? (u32)(a1 >> 32) : (u32)a1, e3 = odd ? (u32)a2 : (u32)(a1 >> 32),
-                              e4 = odd ? (u32)(a2 >> 32) : (u32)a2;
-                    u64 lo = ((u64)__builtin_amdgcn_alignbit(e2, e1, sh) << 32) | __builtin_amdgcn_alignbit(e1, e0, sh);
-                    u64 hi = ((u64)__builtin_amdgcn_alignbit(e4, e3, sh) << 32) | __builtin_amdgcn_alignbit(e3, e2, sh);
-                    const u32 nb = len + (u32)k - 1;
-                    if (nb < 32) {
-                        lo &= ((u64)1 << (2 * nb)) - 1;
-                        hi = 0;
-                    } else {
-                        hi &= ((u64)1 << (2 * (nb - 32))) - 1;
-                    }
-                    // the minimum's position is relative to the first row of the lane that holds the record's last row
-                    const u32 mpos = (end_row & ~31u) + ((u32)(en >> 32) & SK_GPOS_MASK) - start;
-                    const u32 tag = exact ? (mpos & SK_POS_MASK) << (SK_POS_SHIFT - 32) : 1u << (SK_REC_MULTI_BIT - 32);
-                    hi |= ((u64)(len - 1) << 44) | ((u64)dg.d1 << 49) | ((u64)dg.d2 << 59) | ((u64)tag << 32);
-                    ull2_t r;
-                    r.x = lo;
-                    r.y = hi;
-                    if (gslot >= gend[dg.d0])
-                        dropped = true;            // (slab mode: the chunk's slots of this digit are used up)
-                    else if (!SK_DBG(1))
-                        recs[gslot] = r;
-                    else if (r.x == 0x1234567 && r.y == 0x89)
-                        recs[0] = r;
-                }
+        bx.fo = fo;
+        auto build = [&](u32 wrun, bool exact) {
+            if (sk_build<BATCH>(bx, wrun, exact))
+                dropped = true;
         };
         if (f.plain) {
             // records = natural runs: no branch per row -- a lane whose row ends nothing (and lane 63, which owns no rows)
@@ -545,40 +721,9 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                 continue;
             }
         }
-        // the general walk: a partial tile or long runs of one hash (records by hash alone, cut every lmax rows), or a plain
-        // tile whose list overflowed (the SAME records as above -- sk_hist0 counted those -- in four passes of eight row
-        // positions each, which always fit)
-        auto walk = [&](auto byg_tag) {
-            constexpr bool BYG = decltype(byg_tag)::value;
-            sk_front_open<BYG, W>(f, lmax);
-            for (int n_pass = BYG ? 1 : 4, pass = 0; pass < n_pass; pass++) {
-                const int jlo = pass * (32 / n_pass), jhi = jlo + 32 / n_pass;
-                u32 wrun = 0;
-                sk_records_all<BYG, W>(f, lmax, [&](int j, bool end_any, u32 end_row, u32 len, u32 hmin) {
-                    const bool end = end_any && j >= jlo && j < jhi;
-                    const u64 b = __ballot(end);
-                    if (end) {
-                        const u32 pos = wrun + (u32)__popcll(b & below);
-                        if (pos < (u32)SKW_LIST)
-                            wl[pos] = ((u64)hmin << 32) | ((u64)(end_row + 1 - len) << 16) | (u64)end_row;
-                    }
-                    wrun += (u32)__popcll(b);
-                });
-                if (wrun > (u32)SKW_LIST) {        // (only possible in a single pass)
-                    n_pass = 4;
-                    pass = -1;
-                    sk_wave_fence();
-                    continue;
-                }
-                sk_wave_fence();                   // list and words written by other lanes of this wave
-                build(wrun, !BYG);
-                sk_wave_fence();                   // wsh / list are rewritten by the next pass / tile
-            }
-        };
-        if (f.plain)
-            walk(std::false_type{});
-        else
-            walk(std::true_type{});
+        // the general walk (out of line): a partial tile or long runs of one hash, or a plain tile whose list overflowed
+        if (sk_scatter0_general<W, BATCH>(f, bx, words, n_words, tile_pos, lmax, !f.plain))
+            dropped = true;
     }
     if (slab) {
         if (dropped)
@@ -1493,12 +1638,6 @@ constexpr u32 SKC_FREE = ~0u;                    // an empty slot
 __device__ __forceinline__ u64 sk_record_kmer(const ull2_t rec, u32 j, u64 kmask)
 {
     return funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j) & kmask;
-}
-
-// bits [sh, sh + 64) of hi:lo, sh in 0 .. 127
-__device__ __forceinline__ u64 sk_shr128(u64 lo, u64 hi, u32 sh)
-{
-    return sh < 64u ? funnel(lo, hi, sh) : hi >> (sh - 64u);
 }
 
 // Could records A and B -- both cut from plain tiles (SK_REC_MULTI clear), their minimum m-mers equal, at offsets a and b --
