@@ -47,6 +47,9 @@ CONFIGS = {
     3: {"n_bases": 248_956_422, "k": 31, "seed": 0xD2A0002, "kind": "count"},
     4: {"n_bases": 3_000_000_000, "k": 31, "seed": 0xD2A0003, "kind": "count"},      # the headline (default)
     5: {"n_bases": 100_000_000, "k": 21, "seed": 0xD2A0001, "kind": "filter", "pattern": "NNNNNNNNNNWSNNNNNNNNN"},
+    # not a BASELINE.json config: the reference's second counting shape (test.sql:140-150, GROUP BY over a TABLE of
+    # sequences) at read scale -- 10^7 reads of 150 bases in one packed stream (dnagpu_count_kmers_batch)
+    6: {"n_bases": 1_500_000_000, "k": 31, "seed": 0xD2A0006, "kind": "count", "read_len": 150},
 }
 HEADLINE_METRIC = "k-mers/sec for k=31 count over 3 Gbase synthetic; % of HBM-read roofline"
 
@@ -91,7 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config: 2 (k=21 count, 100 Mbase), 3 (k=31 count, chr1 scale), "
-                         "4 (k=31 count, 3 Gbase: the headline, default), 5 (qkmer @> fused into k=21 extraction)")
+                         "4 (k=31 count, 3 Gbase: the headline, default), 5 (qkmer @> fused into k=21 extraction); "
+                         "6 (not in BASELINE.json: k=31 count over a table of 10^7 reads of 150 bases)")
+    ap.add_argument("--read-len", type=int, default=None, help="config 6: bases per read")
     ap.add_argument("--n-bases", type=float, default=None, help="override the config's sequence length")
     ap.add_argument("--k", type=int, default=None, help="override the config's k")
     ap.add_argument("--motif", type=int, default=0,
@@ -181,6 +186,26 @@ def main():
             matches[0] = ctx.count_matches_device(dna, k, flt, 0, n_kmers, C.c_void_p(kb), C.c_void_p(pb), n_kmers)
             for name, ms in ctx.last_phase_times():
                 phases_acc.setdefault(name, []).append(ms)
+    elif world == 1 and cfg.get("read_len"):
+        import numpy as np
+        read_len = args.read_len or cfg["read_len"]
+        n_reads = n_bases // read_len
+        n_bases = n_reads * read_len
+        dna = ctx.synth(seed, n_bases, motif_len=args.motif)
+        starts = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+        n_kmers = n_reads * max(read_len - k + 1, 0)                 # the rows of the table: every read's own
+        extra["table"] = {"reads": n_reads, "read_len": read_len}
+
+        def count_fn(dna_, k_):
+            return ctx.count_kmers_batch(dna_, starts, k_)
+
+        def step():
+            h = count_fn(dna, k)
+            sorted_result[0] = h.is_sorted
+            distinct[0] = h.distinct
+            for name, ms in ctx.last_phase_times():
+                phases_acc.setdefault(name, []).append(ms)
+            h.free()
     elif world == 1:
         dna = ctx.synth(seed, n_bases, motif_len=args.motif)
 
@@ -258,7 +283,7 @@ def main():
             parts_ = torch.tensor([[v >> 32, v & 0xFFFFFFFF] for v in mine], dtype=torch.int64, device=red_dev)
             dist.all_reduce(parts_)
             mine = [((int(hi) << 32) + int(lo)) & 0xFFFFFFFFFFFFFFFF for hi, lo in parts_.tolist()]
-        digest = digest_check(args.config, n_bases, k, seed, args.motif, mine)
+        digest = digest_check(args.config, n_bases, k, seed, args.motif, mine, rows=n_kmers)
 
     if rank == 0 and world == 1 and not is_filter and not sorted_result[0]:
         extra["sorted_view_ms"] = None
@@ -332,7 +357,9 @@ def main():
             metric = HEADLINE_METRIC if (args.config == 4 and n_bases == CONFIGS[4]['n_bases'] and k == CONFIGS[4]['k']) else \
                 f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline"
             eng = "" if world > 1 else (", ordered groups (MSD radix tree)" if sorted_result[0] else ", unordered groups (super-k-mer partitioning)")
-            workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases (splitmix64 seed {seed:#x}"
+            tbl = (f" as a table of {extra['table']['reads']} sequences of {extra['table']['read_len']} bases "
+                   "(dnagpu_count_kmers_batch: no k-mer spans two sequences)") if "table" in extra else ""
+            workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases{tbl} (splitmix64 seed {seed:#x}"
                         f"{', motif ' + str(args.motif) if args.motif else ''}){eng}, "
                         f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, ' + extra.get('exchange', '')}")
             unit = "k-mers/s"
@@ -550,14 +577,14 @@ def digest_key(config, n_bases, k, motif):
     return f"{config}m{motif}" if motif else str(config)
 
 
-def digest_check(config, n_bases, k, seed, motif, got):
+def digest_check(config, n_bases, k, seed, motif, got, rows=None):
     """got = (total, distinct, unique, checksum) summed over the ranks' histograms (dnagpu_hist_summary: the checksum is a
     wrapping sum over groups, so disjoint histograms add up).  Compared with the CPU oracle's digest of the same workload
     (tools/make_digests.py -> tests/golden/config_digests.json).  -> the fields for the JSON line; digest_ok is None when
     the oracle holds no digest for this workload (then only total == rows is checked: digest_total_ok)."""
     total, distinct, unique, checksum = (int(x) for x in got)
     out = {"digest": {"total": total, "distinct": distinct, "unique": unique, "checksum": checksum}}
-    out["digest_total_ok"] = total == n_bases - k + 1
+    out["digest_total_ok"] = total == (n_bases - k + 1 if rows is None else rows)
     key = digest_key(config, n_bases, k, motif)
     want = None
     if key is not None:

@@ -146,6 +146,7 @@ def lib():
     L.dnagpu_hist_download.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u64p, u64p]
     L.dnagpu_hist_summary.argtypes = [vp, vp, u64p, u64p, u64p]
     L.dnagpu_hist_sorted_view.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp]
+    L.dnagpu_hist_merge.argtypes = [vp, vp, vp, C.POINTER(vp)]
     L.dnagpu_hist_free.argtypes = [vp, vp]
     L.dnagpu_hist_free.restype = None
     L.dnagpu_partition_kmers.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp), u64p]
@@ -345,6 +346,12 @@ class Hist:
         t, u, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _chk(lib().dnagpu_hist_summary(self.ctx.h, self.h, C.byref(t), C.byref(u), C.byref(c)))
         return t.value, self.distinct, u.value, c.value
+
+    def merge(self, other):
+        """-> a new Hist: the groups of self and other added up (dnagpu_hist_merge)"""
+        h = C.c_void_p()
+        _chk(lib().dnagpu_hist_merge(self.ctx.h, self.h, other.h, C.byref(h)))
+        return Hist(self.ctx, h)
 
     def free(self):
         if self.h:

@@ -2732,6 +2732,79 @@ extern "C" int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64
     });
 }
 
+// The groups of a and b added up: equal keys' counts are summed.  Both histograms must live on ctx's device; they are
+// left as they are.
+extern "C" int dnagpu_hist_merge(dnagpu_ctx *ctx, const dnagpu_hist *a, const dnagpu_hist *b, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !a || !b || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    *out = nullptr;
+    if (a->total + b->total > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;               // (counts are 32-bit in device memory)
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    PoolScope ps(ctx);
+    const u64 n_max = a->n_distinct + b->n_distinct;
+    u64 t_slots = 1024;
+    while (t_slots < 2 * n_max)
+        t_slots <<= 1;
+    u64 *tkeys = nullptr, *ok = nullptr, *seg_off = nullptr;
+    u32 *tcnt = nullptr, *oc = nullptr, *seg_cnt = nullptr;
+    unsigned long long *ctr = nullptr;             // [0] the all-ones key's count, [1] the groups written
+    RC_TRY(ps.alloc((size_t)t_slots, &tkeys));
+    RC_TRY(ps.alloc((size_t)t_slots, &tcnt));
+    RC_TRY(ps.alloc(2, &ctr));
+    RC_TRY(ps.alloc((size_t)std::max<u64>(n_max, 1), &ok));
+    RC_TRY(ps.alloc((size_t)std::max<u64>(n_max, 1), &oc));
+    RC_TRY(ps.alloc(1, &seg_off));
+    RC_TRY(ps.alloc(1, &seg_cnt));
+    HIP_TRY(hipMemsetAsync(tkeys, 0xFF, (size_t)t_slots * 8, st));
+    HIP_TRY(hipMemsetAsync(tcnt, 0, (size_t)t_slots * 4, st));
+    HIP_TRY(hipMemsetAsync(ctr, 0, 16, st));
+    for (const dnagpu_hist *h : {a, b}) {
+        if (h->parts.empty()) {
+            HIP_TRY(launch_merge_insert(h->keys, h->counts, h->extent ? h->extent : h->n_distinct, tkeys, tcnt, t_slots, ctr, st));
+        } else {
+            for (const dnagpu_hist *p : h->parts)
+                HIP_TRY(launch_merge_insert(p->keys, p->counts, p->extent ? p->extent : p->n_distinct, tkeys, tcnt, t_slots, ctr, st));
+        }
+    }
+    HIP_TRY(launch_merge_compact(tkeys, tcnt, t_slots, ok, oc, ctr + 1, st));
+    u64 res[2] = {0, 0};
+    RC_TRY(read_back(ctx, res, ctr, 16));
+    u64 D = res[1];
+    if (D > n_max) {
+        set_err("hist merge: %llu groups out of %llu", (unsigned long long)D, (unsigned long long)n_max);
+        return DNAGPU_ERR_INTERNAL;
+    }
+    if (res[0]) {                                  // the all-ones key goes last (n_max has room: it was a group of a or b)
+        const u64 kk = ~(u64)0;
+        const u32 cc = (u32)res[0];
+        HIP_TRY(hipMemcpyAsync(ok + D, &kk, 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(oc + D, &cc, 4, hipMemcpyHostToDevice, st));
+        D++;
+    }
+    const u64 zero = 0;
+    const u32 d32 = (u32)D;
+    if (D > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipMemcpyAsync(seg_off, &zero, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(seg_cnt, &d32, 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // group order: the table's -- unspecified, like every unordered histogram's (one segment, not ascending inside)
+    dnagpu_hist *h = new (std::nothrow) dnagpu_hist{ok, oc, D, a->total + b->total, seg_off, seg_cnt, nullptr, 1, false};
+    if (!h)
+        return DNAGPU_ERR_OOM;
+    ps.release(ok);
+    ps.release(oc);
+    ps.release(seg_off);
+    ps.release(seg_cnt);
+    *out = h;
+    return DNAGPU_OK;
+    });
+}
+
 extern "C" void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h)
 {
     if (!h)

@@ -255,6 +255,94 @@ __global__ __launch_bounds__(256) void hist_summary_kernel(const u64 *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dnagpu_hist_merge: the groups of two histograms added up through one open-addressing table in device memory (8-byte
+// keys claimed by compare-and-swap, 32-bit counts added): a utility for callers that count a large table batch by batch,
+// not a hot path -- every group is one random probe.  The all-ones key (32 G's) cannot live in the table: its count is
+// kept apart.
+__global__ __launch_bounds__(256) void merge_insert_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ counts, u64 n,
+                                                           u64 *__restrict__ tkeys, u32 *__restrict__ tcnt, u64 tmask,
+                                                           unsigned long long *__restrict__ ones)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const u32 c = counts[i];
+    if (c == 0)
+        return;                                    // (a padding slot of an unordered histogram)
+    const u64 key = keys[i];
+    if (key == ~(u64)0) {
+        atomicAdd(ones, (unsigned long long)c);
+        return;
+    }
+    u64 h = splitmix64(key) & tmask;
+    for (;;) {
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&tkeys[h]), ~0ull, (unsigned long long)key);
+        if (old == ~(u64)0 || old == key) {
+            atomicAdd(&tcnt[h], c);
+            return;
+        }
+        h = (h + 1) & tmask;
+    }
+}
+
+// the table's groups, dense, in table order: a workgroup reserves the slots of its 4096 table entries with one add
+__global__ __launch_bounds__(256) void merge_compact_kernel(const u64 *__restrict__ tkeys, const u32 *__restrict__ tcnt, u64 t_slots,
+                                                            u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
+                                                            unsigned long long *__restrict__ cursor)
+{
+    __shared__ u32 wsum[4];
+    __shared__ unsigned long long base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 i0 = (u64)blockIdx.x * 4096 + (u64)threadIdx.x * 16;
+    u64 k[16];
+    u32 c[16], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        k[j] = i0 + j < t_slots ? tkeys[i0 + j] : ~(u64)0;
+        c[j] = i0 + j < t_slots ? tcnt[i0 + j] : 0u;
+        mine += k[j] != ~(u64)0 ? 1u : 0u;
+    }
+    const u32 inc = wave_incl_scan(mine);
+    if (lane == 63)
+        wsum[wave] = inc;
+    __syncthreads();
+    u32 before = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+        before += w < wave ? wsum[w] : 0u;
+        total += wsum[w];
+    }
+    if (threadIdx.x == 0)
+        base_s = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    u64 o = base_s + before + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (k[j] != ~(u64)0) {
+            out_keys[o] = k[j];
+            out_counts[o] = c[j];
+            o++;
+        }
+}
+
+hipError_t launch_merge_insert(const u64 *keys, const u32 *counts, u64 n, u64 *tkeys, u32 *tcnt, u64 t_slots,
+                               unsigned long long *ones, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(merge_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, counts, n, tkeys, tcnt, t_slots - 1,
+                       ones);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_compact(const u64 *tkeys, const u32 *tcnt, u64 t_slots, u64 *out_keys, u32 *out_counts,
+                                unsigned long long *cursor, hipStream_t s)
+{
+    hipLaunchKernelGGL(merge_compact_kernel, dim3((unsigned)((t_slots + 4095) / 4096)), dim3(256), 0, s, tkeys, tcnt, t_slots, out_keys,
+                       out_counts, cursor);
+    return hipGetLastError();
+}
+
 hipError_t launch_hist_summary(const u64 *keys, const u32 *counts, u64 n, u64 *result3, hipStream_t s)
 {
     if (n == 0)

@@ -158,6 +158,14 @@ hipError_t launch_gather_sorted(const u64 *seg_off, const u32 *seg_cnt, const u3
                                 u64 first, u64 count, const u64 *keys, const u32 *counts, u64 *dst_keys,
                                 u64 *dst_counts, hipStream_t s);
 
+// ---- dnagpu_hist_merge (extract_kernels.hip): groups (key, count; count 0 = padding) added into an open-addressing table of
+// t_slots (a power of two) 8-byte keys (all ones = free) + 32-bit counts; the all-ones key's count goes to *ones.  Then the
+// table's groups dense, in table order; *cursor (zeroed by the caller) ends as their number.
+hipError_t launch_merge_insert(const u64 *keys, const u32 *counts, u64 n, u64 *tkeys, u32 *tcnt, u64 t_slots,
+                               unsigned long long *ones, hipStream_t s);
+hipError_t launch_merge_compact(const u64 *tkeys, const u32 *tcnt, u64 t_slots, u64 *out_keys, u32 *out_counts,
+                                unsigned long long *cursor, hipStream_t s);
+
 // ---- a table of sequences in one packed stream (extract_kernels.hip)
 // marks: bit b set where a sequence starts at base b (starts[1 .. n_seqs - 1]; the buffer is zeroed here)
 hipError_t launch_batch_marks(const u64 *starts, u64 n_seqs, u32 *marks, u64 n_mark_words, hipStream_t s);

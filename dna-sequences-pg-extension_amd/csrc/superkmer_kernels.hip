@@ -474,7 +474,8 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
                 }
             }
         } else {
-            sk_hist0_general<W, BATCH>(f, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
+            SkFront<W> fm = f;                     // (a copy in memory for the out-of-line walk: f itself stays in registers)
+            sk_hist0_general<W, BATCH>(fm, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
         }
     }
     __syncthreads();
@@ -722,8 +723,12 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             }
         }
         // the general walk (out of line): a partial tile or long runs of one hash, or a plain tile whose list overflowed
-        if (sk_scatter0_general<W, BATCH>(f, bx, words, n_words, tile_pos, lmax, !f.plain))
-            dropped = true;
+        {
+            SkFront<W> fm = f;                     // (a copy in memory for it: f itself stays in registers)
+            const SkBuild bm = bx;
+            if (sk_scatter0_general<W, BATCH>(fm, bm, words, n_words, tile_pos, lmax, !f.plain))
+                dropped = true;
+        }
     }
     if (slab) {
         if (dropped)
@@ -1814,7 +1819,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                 const u32 nba = ((yh >> 12) & 31u) + (u32)k;                     // bases: len + k - 1
                 const u32 v = (u32)funnel(me.x, me.y & (((u64)1 << 34) - 1), 2u * a) & vmask;
                 const u64 mine = (u64)v | ((u64)(u32)tid << 32);
-                u32 slot = (v * 0x9E3779B1u) >> 22;
+                // (NOT the product the fine bucket digits are cut from -- sk_fine_word: every record of this bucket has the
+                // same top 13 bits of that one)
+                u32 slot = ((v ^ (v >> 13)) * 0x85EBCA6Bu) >> 22;
                 for (;;) {
                     const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)mine);
                     if (old == ~(u64)0)

@@ -238,6 +238,13 @@ int dnagpu_hist_sorted_view(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t firs
  * wrapping sum over groups of an order-independent digest of (key, count), computed on device. */
 int dnagpu_hist_summary(dnagpu_ctx *ctx, const dnagpu_hist *h, uint64_t *total, uint64_t *unique,
                         uint64_t *checksum);
+/* *out = the groups of a and b added up (equal keys: counts summed) -- what a caller that counts a large table batch by
+ * batch (dnagpu_count_kmers_batch) does with the batches' histograms; also a PostgreSQL aggregate's combine step.  a and
+ * b stay as they are; all three live on ctx's device.  The result is an unordered histogram of one part (dnagpu_hist_is_sorted
+ * == 0; here the groups are in no order at all, also inside its one segment).  DNAGPU_ERR_TOO_LARGE when the totals pass
+ * 2^32 - 1 (counts are 32-bit in device memory).  A utility (one random probe of a device-memory table per group), not
+ * part of the streaming path. */
+int dnagpu_hist_merge(dnagpu_ctx *ctx, const dnagpu_hist *a, const dnagpu_hist *b, dnagpu_hist **out);
 void dnagpu_hist_free(dnagpu_ctx *ctx, dnagpu_hist *h);
 
 /* ---- multi-GPU sharding of the count (one process per GPU; the exchange itself is the

@@ -1145,6 +1145,47 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
     d.free()
 
 
+@pytest.mark.parametrize("k", [31, 10, 32])
+def test_hist_merge_adds_the_batches_of_a_table(ctx, pkg, k):
+    """dnagpu_hist_merge: a table counted in two batches (dnagpu_count_kmers_batch each) and a repeat-rich single sequence
+    (an unordered histogram with count-0 padding), merged == the oracle's count over all rows; merging with an empty
+    histogram changes nothing; the all-ones key (32 G's) survives the merge."""
+    words, starts = table_of_sequences(0x3E46E + k, 30_000, 60, 400)
+    n = int(starts[-1])
+    cut = 17_000                                       # sequences [0, cut) and [cut, ...) as two packed streams
+    b_cut = int(starts[cut])
+    seqs = orc.dna_decode(words, n)
+    wa, na = orc.dna_encode(seqs[:b_cut])
+    wb, nb = orc.dna_encode(seqs[b_cut:])
+    da, db = ctx.upload(wa, na), ctx.upload(wb, nb)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER if k >= 21 else 0)
+    try:
+        ha = ctx.count_kmers_batch(da, starts[:cut + 1], k)
+        hb = ctx.count_kmers_batch(db, starts[cut:] - np.uint64(b_cut), k)
+        # a third histogram: one sequence with a tiled motif (copies: padding slots in the unordered arrays) and 32 G's
+        wr = orc.synth_words_repeat(5, 400_000, 1000).copy()
+        wr[100:104] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        dr = ctx.upload(wr, 400_000)
+        hr = ctx.count_kmers_unordered(dr, k)
+    finally:
+        ctx.set_debug(0)
+    keys = np.concatenate([orc.generate_kmers_table(words, starts, k), orc.generate_kmers(wr, 400_000, k, faithful=False)])
+    ok, oc = orc.count_keys(keys)
+    hab = ha.merge(hb)
+    hall = hab.merge(hr)
+    assert hall.total == len(keys) and not hall.is_sorted
+    check_hist_unordered(hall, ok, oc, f"merged histograms, k={k}")
+    if k == 32:
+        assert np.uint64(0xFFFFFFFFFFFFFFFF) in ok     # (the key the merge table cannot hold goes through its own counter)
+    empty = ctx.count_kmers_batch(da, starts[:cut + 1], k).merge(ha)      # (sanity: a + a doubles every count)
+    ok2, oc2 = orc.count_keys(orc.generate_kmers_table(wa, starts[:cut + 1], k))
+    check_hist_unordered(empty, ok2, oc2 * np.uint64(2), f"a + a, k={k}")
+    for h in (ha, hb, hr, hab, hall, empty):
+        h.free()
+    for d in (da, db, dr):
+        d.free()
+
+
 def test_count_kmers_batch_is_the_plain_count_for_one_sequence_and_checks_its_arguments(ctx, pkg):
     n = 300_000
     words = orc.synth_words(77, n)

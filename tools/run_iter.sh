@@ -5,7 +5,7 @@ TAG=${1:-iter}; FZ=${2:-300}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python3 -m pytest tests -q -m gpu -x -k "unordered or superkmer or records or level0 or level1 or smoke or config or batch" > $O/pytest.log 2>&1; rc=$?
+timeout -k 10 600 python3 -m pytest tests -q -m gpu -x -k "unordered or superkmer or records or level0 or level1 or smoke or config or batch or merge" > $O/pytest.log 2>&1; rc=$?
 echo "rc=$rc" >> $O/pytest.log; tail -4 $O/pytest.log
 [ $rc -eq 0 ] || exit 1
 timeout -k 10 500 python3 tools/fuzz_unordered.py $FZ > $O/fuzz.log 2>&1; rc=$?; tail -2 $O/fuzz.log
