@@ -1617,11 +1617,12 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   are requested a whole bucket ahead.
 //   RECORDS ARE TESTED BEFORE K-MERS (round 4).  Equal k-mers share their minimum m-mer and its offset inside the k-mer,
 //   so two records cut from plain tiles can hold an equal k-mer only if their m-mers are equal AND they agree around them
-//   (sk_records_share_kmer).  The bucket's ~300 records go into a small table keyed by the m-mer (linear probing: a record
-//   passes every earlier entry of its m-mer on the way to its own slot and is tested against each: ~1.4 pairs per record at
-//   3 Gbase, 0.1 at 250 Mbase); a record that shares a k-mer with no other is CLEAN: each of its k-mers is the only one of
-//   its kind in the bucket and is emitted with count 1 -- no hash, no probe, no slot.  Only the k-mers of the other records
-//   (copies on random sequence: a handful per million; repeats) go through the k-mer table below.  A SK_REC_MULTI record
+//   -- over at least (k - m) / 2 bases on one side.  The bucket's ~300 records go into a small table keyed by the m-mer
+//   (linear probing: a record passes every earlier entry of its m-mer on the way to its own slot and is tested against
+//   each: ~1.4 pairs per record at 3 Gbase, 0.1 at 250 Mbase; the test is two XORs of the packed entries); a record that can
+//   share a k-mer with no other is CLEAN: each of its k-mers is the only one of its kind in the bucket and is emitted with
+//   count 1 -- no hash, no probe, no slot.  Only the k-mers of the other records (random sequence: a few per 10^5; repeats)
+//   go through the k-mer table below, which is exact: the record test only ever errs towards it.  A SK_REC_MULTI record
 //   (low-complexity stretch, the end of the sequence) makes all records of its bucket take the k-mer table.
 //   What bounded it before (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
 //   (9.3 G wave instructions at 3 Gbase: VALU issue 77 % busy, the CU's scalar unit 47 %), not the LDS (23 % busy).
@@ -1711,7 +1712,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     if (tid < SKC_MAXREC)
         rdirty[tid] = 0;
     const u32 mlen = k >= 23 ? 15u : 13u;          // sk_minimizer_len
-    const u32 vmask = (1u << (2u * mlen)) - 1u, kmm = (u32)k - mlen;
+    const u32 vmask = (1u << (2u * mlen)) - 1u;
+    const u32 flank = ((u32)k - mlen) / 2u < 8u ? ((u32)k - mlen) / 2u : 8u, fmask = (1u << (2u * flank)) - 1u;
     const u64 kmask = kmer_mask(k);
     u32 li = list[lq];
     u32 off = list_off[lq];                        // the bucket's output range is [off, off + its k-mers): the exclusive scan of
@@ -1807,34 +1809,44 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         // from a three-dword window of the record that moves on two bits per k-mer (three v_alignbit), slot and
         // fingerprint come from one 32-bit product (the slot through a full-rate 24-bit multiply), and the probe loop
         // carries the slot's byte address only -- what a claim leaves behind is assigned once, after the loop.
-        // ---- the bucket's records against each other (see the head of the kernel)
+        // ---- the bucket's records against each other (see the head of the kernel).  An entry of the record table:
+        //   low word  = 22 bits of a hash of the record's m-mer | record index << 22 (bit 31 clear: no entry is all ones)
+        //   high word = the F bases before the m-mer | the F bases behind it << 16, F = min(8, (k - m) / 2); a side the
+        //               record does not have F bases of holds a value of the record's own (0x8000 | index) instead
+        // Two records can hold an equal k-mer only if their m-mers are equal and they agree over at least F bases right
+        // before or right behind them (an equal k-mer covers the m-mer and k - m >= 2 F more bases around it, aligned at the
+        // m-mer): m-mer hash AND one of the two halves equal.  Such records -- and only a few per million others -- are
+        // marked; their k-mers take the k-mer table, which is exact.
         u32 vslot = ~0u;
         if ((u32)tid < nd.len) {
             const ull2_t me = lrec[tid];
-            const u32 yh = (u32)(me.y >> 32);
+            const u32 p0 = (u32)me.x, p1 = (u32)(me.x >> 32), p2 = (u32)me.y, yh = (u32)(me.y >> 32);
             if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
                 bmulti[par] = 1u;
             } else {
                 const u32 a = (yh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK;
-                const u32 nba = ((yh >> 12) & 31u) + (u32)k;                     // bases: len + k - 1
-                const u32 v = (u32)funnel(me.x, me.y & (((u64)1 << 34) - 1), 2u * a) & vmask;
-                const u64 mine = (u64)v | ((u64)(u32)tid << 32);
-                // (NOT the product the fine bucket digits are cut from -- sk_fine_word: every record of this bucket has the
-                // same top 13 bits of that one)
-                u32 slot = ((v ^ (v >> 13)) * 0x85EBCA6Bu) >> 22;
+                const u32 nba = ((yh >> 12) & 31u) + (u32)k;                     // bases: len + k - 1 (<= 49: payload bits 0 .. 97)
+                const u32 p3 = yh & 3u;
+                const u32 sv = 2u * a, sl = 2u * (a - flank), sr = 2u * (a + mlen);   // bit offsets (sl: only used if a >= flank)
+                const u32 v = __builtin_amdgcn_alignbit(sv >= 32u ? p2 : p1, sv >= 32u ? p1 : p0, sv) & vmask;
+                u32 fl = __builtin_amdgcn_alignbit(sl >= 32u ? p2 : p1, sl >= 32u ? p1 : p0, sl) & fmask;
+                const u32 r_lo = sr >= 64u ? p2 : (sr >= 32u ? p1 : p0), r_hi = sr >= 64u ? p3 : (sr >= 32u ? p2 : p1);
+                u32 fr = __builtin_amdgcn_alignbit(r_hi, r_lo, sr) & fmask;
+                const u32 own = 0x8000u | (u32)tid;
+                fl = a >= flank ? fl : own;
+                fr = nba - a - mlen >= flank ? fr : own;
+                const u32 hv = (v ^ (v >> 13)) * 0x85EBCA6Bu;                    // (not sk_fine_word: the bucket's records share its top bits)
+                const u32 lo32 = (hv >> 10) | ((u32)tid << 22), hi32 = fl | (fr << 16);
+                const u64 mine = (u64)lo32 | ((u64)hi32 << 32);
+                u32 slot = hv >> 22;
                 for (;;) {
                     const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)mine);
                     if (old == ~(u64)0)
                         break;
-                    if ((u32)old == v) {                                         // an earlier record of the same m-mer
-                        const u32 oid = (u32)(old >> 32);
-                        const ull2_t ot = lrec[oid];
-                        const u32 oyh = (u32)(ot.y >> 32);
-                        if (sk_records_share_kmer(me, a, nba, ot, (oyh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK,
-                                                  ((oyh >> 12) & 31u) + (u32)k, mlen, kmm)) {
-                            rdirty[tid] = 1;
-                            rdirty[oid] = 1;
-                        }
+                    const u32 xl = (u32)old ^ lo32, xh = (u32)(old >> 32) ^ hi32;
+                    if ((xl & 0x3FFFFFu) == 0 && ((xh & 0xFFFFu) == 0 || (xh >> 16) == 0)) {
+                        rdirty[tid] = 1;
+                        rdirty[((u32)old >> 22) & 511u] = 1;
                     }
                     slot = (slot + 1u) & (u32)(SKV_SLOTS - 1);
                 }
