@@ -2107,7 +2107,9 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
                               seg_cnt + n_fin, ok, oc, flags, ltmp, cls_list, st, true, small_keys));
     }
     prof_mark(ctx, "sk_count");
-    HIP_TRY(launch_sk_count(fin, list_small, off_small, n_small, recs, k, cursor + 2, seg_off, seg_cnt, ok, oc, st));
+    u32 *left = nullptr;
+    RC_TRY(ps.alloc((size_t)2 * n_small + 1, &left));
+    HIP_TRY(launch_sk_count(fin, list_small, off_small, n_small, recs, k, cursor + 2, seg_off, seg_cnt, ok, oc, left, st));
     prof_mark(ctx, "end");
     u64 fin_ctr[3] = {0, 0, 0};
     RC_TRY(read_back(ctx, fin_ctr, cursor, 24));

@@ -236,8 +236,9 @@ hipError_t launch_sk_regroup(const Node *mids, u32 n_mids, const void *src, void
 // at *cursor, seg_off / seg_cnt[bucket] = where they went
 // list_off[i] = first output slot of bucket list[i] (its range is as long as its k-mers; slots past its distinct keys are
 // count-0 padding); *n_groups += the groups written
+// (left: 2 n_list + 1 words of work memory -- the buckets the record test leaves to the k-mer table kernel)
 hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
-                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s);
+                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *left, hipStream_t s);
 
 int sk_count_cap();       // most k-mers a final bucket may hold to be counted from its records
 hipError_t launch_sk_select_flags(const Node *fin, u32 n_fin, u32 cap, u32 big_limit, u32 *f_small, u32 *f_big, u32 *k_range,

@@ -1604,7 +1604,8 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 }
 
 // ------------------------------------------------------------------------------------------------
-// sk_count: the leaves of the super-k-mer engine.  A final bucket of at most sk_count_cap() k-mers in at most
+// sk_count: the leaves of the super-k-mer engine for the buckets that may hold COPIES (round 4: sk_count_clean below takes
+// every small bucket first and leaves these).  A final bucket of at most sk_count_cap() k-mers in at most
 // SKC_MAXREC records is counted straight from its records in the workgroup's LDS hash table: linear probing over
 // four-byte slots claimed by a 32-bit compare-and-swap, a slot holding 19 bits of fingerprint and the 12-bit id of the
 // k-mer that claimed it; a probe that meets its own fingerprint re-derives the claimant's key from the staged records and
@@ -1615,16 +1616,7 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   gives every quad a thread, and every record writes its quads' owner entries itself -- no search.  Records and
 //   owner table live in LDS, so that nothing between two barriers waits for global memory: the next bucket's records
 //   are requested a whole bucket ahead.
-//   RECORDS ARE TESTED BEFORE K-MERS (round 4).  Equal k-mers share their minimum m-mer and its offset inside the k-mer,
-//   so two records cut from plain tiles can hold an equal k-mer only if their m-mers are equal AND they agree around them
-//   -- over at least (k - m) / 2 bases on one side.  The bucket's ~300 records go into a small table keyed by the m-mer
-//   (linear probing: a record passes every earlier entry of its m-mer on the way to its own slot and is tested against
-//   each: ~1.4 pairs per record at 3 Gbase, 0.1 at 250 Mbase; the test is two XORs of the packed entries); a record that can
-//   share a k-mer with no other is CLEAN: each of its k-mers is the only one of its kind in the bucket and is emitted with
-//   count 1 -- no hash, no probe, no slot.  Only the k-mers of the other records (random sequence: a few per 10^5; repeats)
-//   go through the k-mer table below, which is exact: the record test only ever errs towards it.  A SK_REC_MULTI record
-//   (low-complexity stretch, the end of the sequence) makes all records of its bucket take the k-mer table.
-//   What bounded it before (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
+//   What bounds it (PMC of three variants, round 3): the time follows the kernel's VALU + SALU instruction count
 //   (9.3 G wave instructions at 3 Gbase: VALU issue 77 % busy, the CU's scalar unit 47 %), not the LDS (23 % busy).
 //   Measured and dropped: the quad's four first probes issued back to back (more registers live, a spill); eight k-mers
 //   per thread at 512 threads (half the waves); a binary search over the prefix instead of the owner table; branch-free
@@ -1632,12 +1624,10 @@ __device__ __forceinline__ void sk_wave_prefix16(const u32 *vals, int n, int wav
 //   a per-lane `claimed` flag as a bool (it lives in scalar registers: +44 % SALU, 13.8 ms).
 // Other buckets (flagged by the host's selection) are expanded to keys and counted by the ordinary levels.
 constexpr int SKC_NT = 1024;                     // two workgroups = 32 waves per CU: the kernel lives on hidden latency
-constexpr int SKC_SLOTS = 200 * 64;              // 12800 four-byte slots (load 0.23 if all of 3000 keys go in): with the tables below 76.7 KiB, two workgroups per CU
-constexpr int SKV_SLOTS = 1024;                  // eight-byte slots of the record table (at most SKC_MAXREC = 512 entries)
+constexpr int SKC_SLOTS = 236 * 64;              // 15104 four-byte slots (load 0.2 at 3000 keys): with the tables below 79.0 KiB, two workgroups per CU
 constexpr int SKC_MAXREC = 512;                  // records of a bucket (a bucket of 3300 k-mers of random sequence has ~370)
 constexpr int SKC_KPT = 4;                       // k-mers per quad
 constexpr int SKC_MAXQ = SKC_NT;                 // quads of a bucket: one per thread (the selection sends buckets with more elsewhere)
-static_assert(SKV_SLOTS == SKC_NT, "the record table is cleared by one store per thread");
 constexpr u32 SKC_FREE = ~0u;                    // an empty slot
 
 // k-mer j of a record
@@ -1646,30 +1636,9 @@ __device__ __forceinline__ u64 sk_record_kmer(const ull2_t rec, u32 j, u64 kmask
     return funnel(rec.x, rec.y & (((u64)1 << 44) - 1), 2 * j) & kmask;
 }
 
-// Could records A and B -- both cut from plain tiles (SK_REC_MULTI clear), their minimum m-mers equal, at offsets a and b --
-// hold an equal k-mer?  All k-mers of such a record have their leftmost minimum m-mer at the record's one place, and that
-// offset inside a k-mer is a function of the k-mer's content: equal k-mers K = A[j1 ..] = B[j2 ..] have a - j1 = b - j2.  So
-// the records can only agree where they are aligned at their m-mers, and K covers the m-mer, L' bases before it and R'
-// behind it with L' + R' = k - m: an equal k-mer exists iff the bases agree over L before and R behind the m-mer (as far
-// as BOTH records reach: ML, MR) with L + R >= k - m.  Exact, not a filter.
-__device__ __forceinline__ bool sk_records_share_kmer(const ull2_t A, u32 a, u32 nba, const ull2_t B, u32 b, u32 nbb, u32 m, u32 kmm)
-{
-    const u64 pm = ((u64)1 << 34) - 1;             // payload bits of the second word (at most 49 bases)
-    const u64 ah = A.y & pm, bh = B.y & pm;
-    const u32 ML = a < b ? a : b;
-    const u32 ra = nba - a - m, rb = nbb - b - m;
-    const u32 MR = ra < rb ? ra : rb;               // <= k - m <= 17
-    const u64 xr = (sk_shr128(A.x, ah, 2u * (a + m)) ^ sk_shr128(B.x, bh, 2u * (b + m))) & (((u64)1 << (2u * MR)) - 1);
-    const u32 R = xr ? (u32)__builtin_ctzll(xr) >> 1 : MR;
-    if (R + ML < kmm)
-        return false;
-    const u64 xl = (funnel(A.x, ah, 2u * (a - ML)) ^ funnel(B.x, bh, 2u * (b - ML))) & (((u64)1 << (2u * ML)) - 1);
-    const u32 L = xl ? ML - 1u - ((63u - (u32)__builtin_clzll(xl)) >> 1) : ML;
-    return L + R >= kmm;
-}
-
 __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
-                                                             const u32 *__restrict__ list_off, u32 n_list,
+                                                             const u32 *__restrict__ list_off, u32 n_list_arg,
+                                                             const u32 *__restrict__ n_list_dev /* or null */,
                                                              const ull2_t *__restrict__ recs, int k,
                                                              unsigned long long *__restrict__ n_groups,
                                                              u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
@@ -1690,13 +1659,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
     __shared__ unsigned short ownq[SKC_MAXQ];      // quad -> record | first k-mer / SKC_KPT << 9
     __shared__ u32 wclaim[2][WAVES], wq[RWAVES];
     __shared__ u32 copy_seen[2];
-    // the record table: m-mer value | record index << 32 (all ones: free); rdirty[r]: record r shares a k-mer with another;
-    // bmulti: the bucket holds a SK_REC_MULTI record
-    __shared__ __attribute__((aligned(16))) u64 vtab[SKV_SLOTS];
-    __shared__ unsigned char rdirty[SKC_MAXREC];
-    __shared__ u32 bmulti[2];
     int tid = threadIdx.x;
     int lane = tid & 63, wave = tid >> 6;
+    const u32 n_list = n_list_dev ? *n_list_dev : n_list_arg;      // (the buckets sk_count_clean left: counted on the device)
     u32 lq = blockIdx.x;
     if (lq >= n_list)
         return;
@@ -1704,16 +1669,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         tab[q] = SKC_FREE;
     for (int q = tid; q < SKC_NT * SKC_KPT / 2; q += SKC_NT)
         cop2[q] = 0;
-    if (tid < 2) {
+    if (tid < 2)
         copy_seen[tid] = 0;
-        bmulti[tid] = 0;
-    }
-    vtab[tid] = ~(u64)0;                           // (SKV_SLOTS == SKC_NT)
-    if (tid < SKC_MAXREC)
-        rdirty[tid] = 0;
-    const u32 mlen = k >= 23 ? 15u : 13u;          // sk_minimizer_len
-    const u32 vmask = (1u << (2u * mlen)) - 1u;
-    const u32 flank = ((u32)k - mlen) / 2u < 8u ? ((u32)k - mlen) / 2u : 8u, fmask = (1u << (2u * flank)) - 1u;
     const u64 kmask = kmer_mask(k);
     u32 li = list[lq];
     u32 off = list_off[lq];                        // the bucket's output range is [off, off + its k-mers): the exclusive scan of
@@ -1809,53 +1766,9 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         // from a three-dword window of the record that moves on two bits per k-mer (three v_alignbit), slot and
         // fingerprint come from one 32-bit product (the slot through a full-rate 24-bit multiply), and the probe loop
         // carries the slot's byte address only -- what a claim leaves behind is assigned once, after the loop.
-        // ---- the bucket's records against each other (see the head of the kernel).  An entry of the record table:
-        //   low word  = 22 bits of a hash of the record's m-mer | record index << 22 (bit 31 clear: no entry is all ones)
-        //   high word = the F bases before the m-mer | the F bases behind it << 16, F = min(8, (k - m) / 2); a side the
-        //               record does not have F bases of holds a value of the record's own (0x8000 | index) instead
-        // Two records can hold an equal k-mer only if their m-mers are equal and they agree over at least F bases right
-        // before or right behind them (an equal k-mer covers the m-mer and k - m >= 2 F more bases around it, aligned at the
-        // m-mer): m-mer hash AND one of the two halves equal.  Such records -- and only a few per million others -- are
-        // marked; their k-mers take the k-mer table, which is exact.
-        u32 vslot = ~0u;
-        if ((u32)tid < nd.len) {
-            const ull2_t me = lrec[tid];
-            const u32 p0 = (u32)me.x, p1 = (u32)(me.x >> 32), p2 = (u32)me.y, yh = (u32)(me.y >> 32);
-            if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
-                bmulti[par] = 1u;
-            } else {
-                const u32 a = (yh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK;
-                const u32 nba = ((yh >> 12) & 31u) + (u32)k;                     // bases: len + k - 1 (<= 49: payload bits 0 .. 97)
-                const u32 p3 = yh & 3u;
-                const u32 sv = 2u * a, sl = 2u * (a - flank), sr = 2u * (a + mlen);   // bit offsets (sl: only used if a >= flank)
-                const u32 v = __builtin_amdgcn_alignbit(sv >= 32u ? p2 : p1, sv >= 32u ? p1 : p0, sv) & vmask;
-                u32 fl = __builtin_amdgcn_alignbit(sl >= 32u ? p2 : p1, sl >= 32u ? p1 : p0, sl) & fmask;
-                const u32 r_lo = sr >= 64u ? p2 : (sr >= 32u ? p1 : p0), r_hi = sr >= 64u ? p3 : (sr >= 32u ? p2 : p1);
-                u32 fr = __builtin_amdgcn_alignbit(r_hi, r_lo, sr) & fmask;
-                const u32 own = 0x8000u | (u32)tid;
-                fl = a >= flank ? fl : own;
-                fr = nba - a - mlen >= flank ? fr : own;
-                const u32 hv = (v ^ (v >> 13)) * 0x85EBCA6Bu;                    // (not sk_fine_word: the bucket's records share its top bits)
-                const u32 lo32 = (hv >> 10) | ((u32)tid << 22), hi32 = fl | (fr << 16);
-                const u64 mine = (u64)lo32 | ((u64)hi32 << 32);
-                u32 slot = hv >> 22;
-                for (;;) {
-                    const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)mine);
-                    if (old == ~(u64)0)
-                        break;
-                    const u32 xl = (u32)old ^ lo32, xh = (u32)(old >> 32) ^ hi32;
-                    if ((xl & 0x3FFFFFu) == 0 && ((xh & 0xFFFFu) == 0 || (xh >> 16) == 0)) {
-                        rdirty[tid] = 1;
-                        rdirty[((u32)old >> 22) & 511u] = 1;
-                    }
-                    slot = (slot + 1u) & (u32)(SKV_SLOTS - 1);
-                }
-                vslot = slot;
-            }
-        }
         u32 ckl[KEEP], ckh[KEEP];
         u32 cslot[KEEP];                           // byte address of the claimed slot
-        u32 c_mask = 0, s_mask = 0;                // k-mers of the quad that are groups of their own / that hold a slot of the table
+        u32 c_mask = 0;
         // (only positions whose c_mask bit is set are ever used: the others stay whatever their registers hold -- defined
         // for the compiler by an empty asm, so that no instruction initialises them: 12 moves per thread and bucket)
 #pragma unroll
@@ -1864,22 +1777,20 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             asm volatile("" : "=v"(ckh[q]));
             asm volatile("" : "=v"(cslot[q]));
         }
-        const bool has_quad = (u32)tid < n_quads;
-        u32 qrec = 0, rl = 0, j0 = 0;              // the quad's record, its k-mers, the quad's first
-        if (has_quad) {
+        if ((u32)tid < n_quads) {
             const u32 e = ownq[tid];
-            qrec = e & 511u;
-            const ull2_t rec = lrec[qrec];
+            const ull2_t rec = lrec[e & 511u];
             const u32 p0 = (u32)rec.x, p1 = (u32)(rec.x >> 32), p2 = (u32)rec.y, p3h = (u32)(rec.y >> 32);
-            rl = ((p3h >> 12) & 31u) + 1u;
+            const u32 rl = ((p3h >> 12) & 31u) + 1u;
             const u32 p3 = p3h & 0xFFFu;
-            j0 = (e >> 9) * SKC_KPT;
+            const u32 j0 = (e >> 9) * SKC_KPT;
             const bool up = j0 >= 16;                            // the quad starts in the record's second dword
             const u32 sh = (2 * j0) & 31u;
             const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2, a3 = up ? 0u : p3;
             u32 w0 = __builtin_amdgcn_alignbit(a1, a0, sh), w1 = __builtin_amdgcn_alignbit(a2, a1, sh),
                 w2 = __builtin_amdgcn_alignbit(a3, a2, sh);
             const u32 hmask = (u32)(kmask >> 32);                // (k >= 21: the low dword is whole)
+            const u32 id0 = (u32)tid << 2;
             // all four keys of the quad first, straight into the registers that keep them (the window moves on two bits per
             // k-mer whether the position exists or not: no copies where the branches of the inserts meet)
 #pragma unroll
@@ -1890,17 +1801,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                 w1 = __builtin_amdgcn_alignbit(w2, w1, 2);
                 w2 >>= 2;
             }
-        }
-        __syncthreads();                           // R: every record tested
-        if (vslot != ~0u)
-            vtab[vslot] = ~(u64)0;                 // (the table is clean again for the next bucket)
-        if (has_quad) {
-            const u32 id0 = (u32)tid << 2;
-            const u32 nk = rl - j0 < (u32)SKC_KPT ? rl - j0 : (u32)SKC_KPT;
-            if (!(bmulti[par] | rdirty[qrec])) {
-                // a clean record: each of its k-mers is the only one of its kind in the bucket
-                c_mask = (1u << nk) - 1u;
-            } else
 #pragma unroll
             for (int q = 0; q < SKC_KPT; q++) {
                 if (j0 + (u32)q < rl) {
@@ -1918,7 +1818,6 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
                             const u32 old = atomicCAS(reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + sa), SKC_FREE, word);
                             if (old == SKC_FREE) {
                                 c_mask |= 1u << q;
-                                s_mask |= 1u << q;
                                 break;
                             }
                             if ((old ^ word) < 4096u) {
@@ -1962,9 +1861,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
             pkl[q] = ckl[q];
             pkh[q] = ckh[q];
             pc[q] = 0;
-            if ((c_mask >> q) & 1u)
+            if ((c_mask >> q) & 1u) {
                 pc[q] = 1u;
-            if ((s_mask >> q) & 1u) {
                 *reinterpret_cast<u32 *>(reinterpret_cast<char *>(tab) + cslot[q]) = SKC_FREE;
                 if (any_copy) {
                     const u32 copies = cop16[(u32)tid * SKC_KPT + (u32)q];
@@ -1983,11 +1881,8 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         p_copy = any_copy;
         if (tid == 0) {
             my_groups += D;
-            copy_seen[par ^ 1] = 0;                // (the other parity's flags: its bucket is done with them)
-            bmulti[par ^ 1] = 0;
+            copy_seen[par ^ 1] = 0;                // (the other parity's flag: its bucket is done with it)
         }
-        if (tid < SKC_MAXREC)
-            rdirty[tid] = 0;                       // (read between R and B only; the next bucket's tests start behind A2)
         have_prev = true;
         par ^= 1;
         if (!has_next)
@@ -2020,18 +1915,220 @@ __global__ __launch_bounds__(SKC_NT, 8) void sk_count_kernel(const Node *__restr
         atomicAdd(n_groups, (unsigned long long)my_groups);
 }
 
+// Could records A and B -- both cut from plain tiles (SK_REC_MULTI clear), their minimum m-mers equal, at offsets a and b --
+// hold an equal k-mer?  All k-mers of such a record have their leftmost minimum m-mer at the record's one place, and that
+// offset inside a k-mer is a function of the k-mer's content: equal k-mers K = A[j1 ..] = B[j2 ..] have a - j1 = b - j2.  So
+// the records can only agree where they are aligned at their m-mers, and K covers the m-mer, L' bases before it and R'
+// behind it with L' + R' = k - m: an equal k-mer exists iff the bases agree over L before and R behind the m-mer (as far
+// as BOTH records reach: ML, MR) with L + R >= k - m.  Exact, not a filter.
+__device__ __forceinline__ bool sk_records_share_kmer(const ull2_t A, u32 a, u32 nba, const ull2_t B, u32 b, u32 nbb, u32 m, u32 kmm)
+{
+    const u64 pm = ((u64)1 << 34) - 1;             // payload bits of the second word (at most 49 bases)
+    const u64 ah = A.y & pm, bh = B.y & pm;
+    const u32 ML = a < b ? a : b;
+    const u32 ra = nba - a - m, rb = nbb - b - m;
+    const u32 MR = ra < rb ? ra : rb;               // <= k - m <= 17
+    const u64 xr = (sk_shr128(A.x, ah, 2u * (a + m)) ^ sk_shr128(B.x, bh, 2u * (b + m))) & (((u64)1 << (2u * MR)) - 1);
+    const u32 R = xr ? (u32)__builtin_ctzll(xr) >> 1 : MR;
+    if (R + ML < kmm)
+        return false;
+    const u64 xl = (funnel(A.x, ah, 2u * (a - ML)) ^ funnel(B.x, bh, 2u * (b - ML))) & (((u64)1 << (2u * ML)) - 1);
+    const u32 L = xl ? ML - 1u - ((63u - (u32)__builtin_clzll(xl)) >> 1) : ML;
+    return L + R >= kmm;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// sk_count_clean (round 4): RECORDS ARE TESTED BEFORE K-MERS.  Equal k-mers share their minimum m-mer AND its offset inside
+// the k-mer (both are functions of the k-mer's content), so two records cut from plain tiles can hold an equal k-mer only
+// if their m-mers are equal and they agree around them -- over L bases before and R behind it with L + R >= k - m
+// (sk_records_share_kmer: exact).  A bucket's ~300 records go into a small LDS table keyed by the m-mer: an entry is
+//   low word  = 22 bits of a hash of the m-mer | record index << 22 (bit 31 clear: no entry is all ones)
+//   high word = the F bases before the m-mer | the F bases behind it << 16, F = min(8, (k - m) / 2); a side the record
+//               does not have F bases of holds a value of the record's own (0x8000 | index) instead
+// (linear probing: a record passes every earlier entry of its m-mer on the way to its own slot: ~1.4 of them at 3 Gbase,
+// 0.1 at 250 Mbase).  An equal k-mer covers the m-mer and k - m >= 2 F more bases around it, so it needs the m-mer's hash
+// and one of the two halves equal: two XORs per passed entry; the few pairs that pass (4^-F per side) take the exact test.
+// A bucket in which no two records share a k-mer holds every k-mer ONCE: its k-mers are cut from the records and leave as
+// (key, 1) groups, one k-mer per thread and round, 8 + 4 bytes per lane to consecutive addresses -- no k-mer hash, no probe,
+// no table.  Every other bucket (copies: a handful per million on random sequence; repeats; a SK_REC_MULTI record of a
+// low-complexity stretch) is appended to a list that sk_count takes afterwards, exact as before.
+//   Why: round 3's sk_count spent 265 vector + 200 scalar instructions per wave and bucket, a third of them probing the
+//   k-mer table for k-mers that never had a copy, the rest bookkeeping around sixteen waves (quads, claim prefixes, keys
+//   kept a bucket long, four ballot rounds of stores).  This kernel has eight waves per bucket, no table to clear, and
+//   26 KB of LDS: four workgroups per CU.
+constexpr int SKQ_NT = 512;
+static_assert(SKQ_NT == SKC_MAXREC, "a thread per record");
+constexpr int SKQ_KMERS = 4096;                  // sk_count_cap(): most k-mers of a small bucket
+constexpr int SKQ_VSLOTS = 1024;                 // record table (at most 512 entries)
+
+__global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
+                                                                   const u32 *__restrict__ list_off, u32 n_list,
+                                                                   const ull2_t *__restrict__ recs, int k,
+                                                                   unsigned long long *__restrict__ n_groups,
+                                                                   u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
+                                                                   u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
+                                                                   u32 *__restrict__ left_list, u32 *__restrict__ left_off,
+                                                                   u32 *__restrict__ n_left)
+{
+    constexpr int WAVES = SKQ_NT / 64;
+    __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
+    __shared__ __attribute__((aligned(16))) u64 vtab[SKQ_VSLOTS];
+    __shared__ unsigned short own[SKQ_KMERS];      // k-mer of the bucket -> record | position in it << 9
+    __shared__ u32 wk[WAVES];
+    __shared__ u32 shared_flag[2];                 // by bucket parity: the bucket goes to sk_count
+    int tid = threadIdx.x;
+    u32 lq = blockIdx.x;
+    if (lq >= n_list)
+        return;
+    vtab[tid] = ~(u64)0;
+    vtab[tid + SKQ_NT] = ~(u64)0;
+    if (tid < 2)
+        shared_flag[tid] = 0;
+    const u32 mlen = k >= 23 ? 15u : 13u;          // sk_minimizer_len
+    const u32 vmask = (1u << (2u * mlen)) - 1u, kmm = (u32)k - mlen;
+    const u32 flank = kmm / 2u < 8u ? kmm / 2u : 8u, fmask = (1u << (2u * flank)) - 1u;
+    const u32 hmask = (u32)(kmer_mask(k) >> 32);   // (k >= 21: the low dword of a key is whole)
+    const u32 step = gridDim.x;
+    u32 li = list[lq];
+    Node nd = fin[li];
+    ull2_t myrec;
+    myrec.x = myrec.y = 0;
+    if ((u32)tid < nd.len)
+        myrec = recs[(u64)nd.start + tid];
+    u64 my_groups = 0;
+    int par = 0;
+    for (;;) {
+        const u32 off = list_off[lq];
+        const bool has_next = lq + step < n_list;
+        const u32 ln = has_next ? list[lq + step] : li;
+        const Node nn = fin[ln];
+        asm volatile("" : "+v"(tid));              // (nothing derived from the thread index is held across buckets)
+        const int lane = tid & 63, wave = tid >> 6;
+        // ---- this bucket's records into LDS, the next bucket's requested
+        const ull2_t me = myrec;
+        lrec[tid] = me;
+        myrec.x = myrec.y = 0;
+        if (has_next && (u32)tid < nn.len)
+            myrec = recs[(u64)nn.start + tid];
+        const bool have = (u32)tid < nd.len;
+        const u32 yh = (u32)(me.y >> 32);
+        const u32 len = have ? ((yh >> 12) & 31u) + 1u : 0u;
+        const u32 kinc = wave_incl_scan(len);
+        if (lane == 63)
+            wk[wave] = kinc;
+        __syncthreads();                           // (1) lrec / wk complete; the previous bucket's readers are done (barrier 3)
+        u32 kbase = 0, n_km = 0;
+        sk_wave_prefix16(wk, WAVES, wave, lane, kbase, n_km);
+        // ---- every k-mer's owner; the records against each other
+        u32 vslot = ~0u;
+        if (have) {
+            const u32 k0 = kbase + kinc - len;
+            for (u32 j = 0; j < len; j++)
+                own[k0 + j] = (unsigned short)((u32)tid | (j << 9));
+            if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
+                shared_flag[par] = 1u;             // (nothing is known about where this record's m-mer is)
+            } else {
+                const u32 p0 = (u32)me.x, p1 = (u32)(me.x >> 32), p2 = (u32)me.y, p3 = yh & 3u;
+                const u32 a = (yh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK;
+                const u32 nba = len + (u32)k - 1u;                                // bases (<= 49: payload bits 0 .. 97)
+                const u32 sv = 2u * a, sl = 2u * (a - flank), sr = 2u * (a + mlen);   // bit offsets (sl: only used if a >= flank)
+                const u32 v = __builtin_amdgcn_alignbit(sv >= 32u ? p2 : p1, sv >= 32u ? p1 : p0, sv) & vmask;
+                u32 fl = __builtin_amdgcn_alignbit(sl >= 32u ? p2 : p1, sl >= 32u ? p1 : p0, sl) & fmask;
+                const u32 r_lo = sr >= 64u ? p2 : (sr >= 32u ? p1 : p0), r_hi = sr >= 64u ? p3 : (sr >= 32u ? p2 : p1);
+                u32 fr = __builtin_amdgcn_alignbit(r_hi, r_lo, sr) & fmask;
+                const u32 mine_own = 0x8000u | (u32)tid;
+                fl = a >= flank ? fl : mine_own;
+                fr = nba - a - mlen >= flank ? fr : mine_own;
+                const u32 hv = (v ^ (v >> 13)) * 0x85EBCA6Bu;                    // (not sk_fine_word: the bucket's records share its top bits)
+                const u32 lo32 = (hv >> 10) | ((u32)tid << 22), hi32 = fl | (fr << 16);
+                const u64 mine = (u64)lo32 | ((u64)hi32 << 32);
+                u32 slot = hv >> 22;
+                for (;;) {
+                    const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)mine);
+                    if (old == ~(u64)0)
+                        break;
+                    const u32 xl = (u32)old ^ lo32, xh = (u32)(old >> 32) ^ hi32;
+                    if ((xl & 0x3FFFFFu) == 0 && ((xh & 0xFFFFu) == 0 || (xh >> 16) == 0)) {
+                        // (rare: 4^-F per side and pair) the exact test
+                        const u32 oid = ((u32)old >> 22) & 511u;
+                        const ull2_t ot = lrec[oid];
+                        const u32 oyh = (u32)(ot.y >> 32);
+                        if (sk_records_share_kmer(me, a, nba, ot, (oyh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK,
+                                                  ((oyh >> 12) & 31u) + (u32)k, mlen, kmm))
+                            shared_flag[par] = 1u;
+                    }
+                    slot = (slot + 1u) & (u32)(SKQ_VSLOTS - 1);
+                }
+                vslot = slot;
+            }
+        }
+        __syncthreads();                           // (2) owners and the verdict complete
+        if (vslot != ~0u)
+            vtab[vslot] = ~(u64)0;                 // (the table is clean again for the next bucket)
+        if (shared_flag[par]) {
+            if (tid == 0) {                        // two records may share a k-mer: the bucket is sk_count's
+                const u32 d = atomicAdd(n_left, 1u);
+                left_list[d] = li;
+                left_off[d] = off;
+            }
+        } else {
+            // ---- every k-mer of the bucket is the only one of its kind: (key, 1) groups, k-mer i at slot off + i
+            u64 *ok = out_keys + off;
+            u32 *oc = out_counts + off;
+            for (u32 i = (u32)tid; i < n_km; i += SKQ_NT) {
+                const u32 e = own[i];
+                const ull2_t r = lrec[e & 511u];
+                const u32 p0 = (u32)r.x, p1 = (u32)(r.x >> 32), p2 = (u32)r.y, p3 = (u32)(r.y >> 32) & 3u;
+                const u32 sh = 2u * (e >> 9);      // (<= 2 (w - 1) = 34)
+                const bool up = sh >= 32u;
+                const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2;
+                const u32 kl = __builtin_amdgcn_alignbit(a1, a0, sh), kh = __builtin_amdgcn_alignbit(a2, a1, sh) & hmask;
+                ok[i] = ((u64)kh << 32) | kl;
+                oc[i] = 1u;
+            }
+            if (tid == 0) {
+                seg_off[li] = off;
+                seg_cnt[li] = n_km;
+                my_groups += n_km;
+            }
+        }
+        if (tid == 0)
+            shared_flag[par ^ 1] = 0;              // (the other parity's flag: its bucket is done with it)
+        par ^= 1;
+        if (!has_next)
+            break;
+        __syncthreads();                           // (3) lrec / own are rewritten by the next bucket
+        lq += step;
+        li = ln;
+        nd = nn;
+    }
+    if (tid == 0 && my_groups)
+        atomicAdd(n_groups, (unsigned long long)my_groups);
+}
+
 static int sk_dbg();
 
 hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off, u32 n_list, const void *recs, int k, u64 *n_groups,
-                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, hipStream_t s)
+                           u64 *seg_off, u32 *seg_cnt, u64 *out_keys, u32 *out_counts, u32 *left /* 2 n_list + 1 words */,
+                           hipStream_t s)
 {
     if (n_list == 0)
         return hipSuccess;
     int dev = 0, n_cu = 256, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
         n_cu = v;
+    // every small bucket through the record test first; the ones that may hold copies are listed (left[0 .. n), left[n_list ..
+    // n_list + n) = their output offsets, left[2 n_list] = n) and counted by the k-mer table kernel behind it
+    u32 *left_list = left, *left_off = left + n_list, *n_left = left + 2 * (size_t)n_list;
+    hipError_t e = hipMemsetAsync(n_left, 0, sizeof(u32), s);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(sk_count_clean_kernel, dim3(std::min<u32>(n_list, (u32)n_cu * 4u)), dim3(SKQ_NT), 0, s, fin, list, list_off, n_list,
+                       reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
+                       out_keys, out_counts, left_list, left_off, n_left);
     const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
-    hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, list, list_off, n_list,
+    hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, left_list, left_off, 0u, n_left,
                        reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
                        out_keys, out_counts, sk_dbg());
     return hipGetLastError();
