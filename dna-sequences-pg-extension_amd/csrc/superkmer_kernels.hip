@@ -1969,7 +1969,7 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                                                                    u64 *__restrict__ seg_off, u32 *__restrict__ seg_cnt,
                                                                    u64 *__restrict__ out_keys, u32 *__restrict__ out_counts,
                                                                    u32 *__restrict__ left_list, u32 *__restrict__ left_off,
-                                                                   u32 *__restrict__ n_left)
+                                                                   u32 *__restrict__ n_left, int dbg)
 {
     constexpr int WAVES = SKQ_NT / 64;
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
@@ -2024,9 +2024,11 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
         u32 vslot = ~0u;
         if (have) {
             const u32 k0 = kbase + kinc - len;
-            for (u32 j = 0; j < len; j++)
-                own[k0 + j] = (unsigned short)((u32)tid | (j << 9));
-            if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
+            if (!SK_DBG(1024))
+                for (u32 j = 0; j < len; j++)
+                    own[k0 + j] = (unsigned short)((u32)tid | (j << 9));
+            if (SK_DBG(256)) {
+            } else if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
                 shared_flag[par] = 1u;             // (nothing is known about where this record's m-mer is)
             } else {
                 const u32 p0 = (u32)me.x, p1 = (u32)(me.x >> 32), p2 = (u32)me.y, p3 = yh & 3u;
@@ -2074,9 +2076,11 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
             }
         } else {
             // ---- every k-mer of the bucket is the only one of its kind: (key, 1) groups, k-mer i at slot off + i
+            // Two k-mers per thread and round: 16 bytes of keys and 8 of counts per lane, nontemporal (a plain store stream
+            // tops out near 3.3 TB/s on this chip); the pairs start on an even output slot.
             u64 *ok = out_keys + off;
             u32 *oc = out_counts + off;
-            for (u32 i = (u32)tid; i < n_km; i += SKQ_NT) {
+            auto key_of = [&](u32 i) -> u64 {
                 const u32 e = own[i];
                 const ull2_t r = lrec[e & 511u];
                 const u32 p0 = (u32)r.x, p1 = (u32)(r.x >> 32), p2 = (u32)r.y, p3 = (u32)(r.y >> 32) & 3u;
@@ -2084,8 +2088,28 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                 const bool up = sh >= 32u;
                 const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2;
                 const u32 kl = __builtin_amdgcn_alignbit(a1, a0, sh), kh = __builtin_amdgcn_alignbit(a2, a1, sh) & hmask;
-                ok[i] = ((u64)kh << 32) | kl;
-                oc[i] = 1u;
+                return ((u64)kh << 32) | kl;
+            };
+            const u32 odd = off & 1u;
+            if (odd && tid == 0 && n_km) {
+                __builtin_nontemporal_store(key_of(0), &ok[0]);
+                __builtin_nontemporal_store(1u, &oc[0]);
+            }
+            for (u32 i = odd + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
+                const u64 k0 = key_of(i);
+                if (SK_DBG(512)) {
+                    if (k0 == 0x123456789ull)
+                        ok[0] = k0;
+                } else if (i + 1 < n_km) {
+                    ull2_t kk;
+                    kk.x = k0;
+                    kk.y = key_of(i + 1);
+                    __builtin_nontemporal_store(kk, reinterpret_cast<ull2_t *>(&ok[i]));
+                    __builtin_nontemporal_store((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
+                } else {
+                    __builtin_nontemporal_store(k0, &ok[i]);
+                    __builtin_nontemporal_store(1u, &oc[i]);
+                }
             }
             if (tid == 0) {
                 seg_off[li] = off;
@@ -2126,7 +2150,7 @@ hipError_t launch_sk_count(const Node *fin, const u32 *list, const u32 *list_off
         return e;
     hipLaunchKernelGGL(sk_count_clean_kernel, dim3(std::min<u32>(n_list, (u32)n_cu * 4u)), dim3(SKQ_NT), 0, s, fin, list, list_off, n_list,
                        reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
-                       out_keys, out_counts, left_list, left_off, n_left);
+                       out_keys, out_counts, left_list, left_off, n_left, sk_dbg());
     const u32 grid = std::min<u32>(n_list, (u32)n_cu * 2u);
     hipLaunchKernelGGL(sk_count_kernel, dim3(grid), dim3(SKC_NT), 0, s, fin, left_list, left_off, 0u, n_left,
                        reinterpret_cast<const ull2_t *>(recs), k, reinterpret_cast<unsigned long long *>(n_groups), seg_off, seg_cnt,
