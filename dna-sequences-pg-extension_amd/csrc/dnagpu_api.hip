@@ -1366,7 +1366,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
 // DNAGPU_SK_SKEWED: a bucket is too heavy (low-complexity input): the caller counts with the ordinary tree
 // instead, which has the skew paths.
 constexpr int DNAGPU_SK_SKEWED = -1;
-constexpr u64 SK_LEAF_MEAN = 2700;               // planned k-mers per final bucket: ~850 quads of four k-mers, 1024 (sk_count's threads) is 3 sigma above
+constexpr u64 SK_LEAF_MEAN = 2500;               // planned k-mers per final bucket: ~770 quads of four k-mers -- 1024 (sk_count's threads: the buckets with copies) is 4 sigma above, so next to no bucket takes the expansion path (A/B on one box, 3 Gbase: 2700 18.7 - 18.8 ms, 2500 18.2, 2300 18.1 - 18.4)
 // A mid bucket of more than SK_MID_LIMIT k-mers (planned: 16 x SK_LEAF_MEAN) is "heavy" and leaves the record path for the
 // expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
 // few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
