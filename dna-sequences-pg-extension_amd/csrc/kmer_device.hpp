@@ -134,10 +134,17 @@ __device__ __forceinline__ u32 wave_sum(u32 x)
 // caller has synchronised before the call; the function synchronises before returning.  tid = the caller's thread index
 // (callers that keep it opaque per tile -- so that nothing derived from it is held across their tile loops -- pass that one).
 template <int NT>
+__device__ __forceinline__ u32 block_scan_value(u32 v, u32 *arr, int n, u32 *wtmp, int tid);
+template <int NT>
 __device__ __forceinline__ u32 block_scan_small(u32 *arr, int n, u32 *wtmp, int tid)
 {
+    return block_scan_value<NT>(tid < n ? arr[tid] : 0u, arr, n, wtmp, tid);
+}
+// the same with thread tid's element handed over as a value (0 for tid >= n): arr[tid] = the sum of the elements before it
+template <int NT>
+__device__ __forceinline__ u32 block_scan_value(u32 v, u32 *arr, int n, u32 *wtmp, int tid)
+{
     const int lane = tid & 63, wave = tid >> 6;
-    const u32 v = tid < n ? arr[tid] : 0;
     const u32 inc = wave_incl_scan(v);
     if (lane == 63)
         wtmp[wave] = inc;

@@ -60,16 +60,17 @@ constexpr int SK_POS_SHIFT = 39;                 // (k-mers of the record never 
 constexpr u32 SK_POS_MASK = 31u;
 constexpr u32 SK_GPOS_MASK = 63u;                // low bits of a window minimum: the position of the minimum (see sk_front)
 
-// bijective 32-bit mix of the 30-bit m-mer value: distinct m-mers never tie.  Four operations (the sweeps of level 0 are
-// bound by VALU instruction issue: 36 per row in round 2, 9 of them this hash): on random sequence the order it gives
-// makes runs as long as the seven-operation mix it replaces (8.99 k-mers per record at k = 31; tools/hash_eval.py).
-__device__ __forceinline__ u32 sk_mix(u32 h)
+// 32-bit hash of an m-mer value (2 m <= 30 bits; bits above them ignored: t may carry a 16th base): two full-rate 24-bit
+// multiplies, t[0..24) C1 + t[24..2m) C2 -- v_mul_u32_u24 + v_mad_u32_u24 behind one v_bfe (round 3's shift / add / xor mix
+// took four operations behind a mask: the sweeps of level 0 are bound by VALU issue).  Its top 25 bits order the m-mers
+// (sk_front): on random sequence that order makes runs as long as the old one (8.997 k-mers per record at k = 31 against
+// 8.995) and the coarse buckets as even (tools/hash_eval2.py).  Not injective on its 25 bits, and it need not be: records
+// are compared by their m-mers' VALUES wherever it matters (sk_count_clean, the walks by value).
+__device__ __forceinline__ u32 sk_mix_raw(u32 t, u32 hi_bits /* 2 m - 24 */)
 {
-    h += h << 11;                                 // (two shift-adds in a row would be fused into one quarter-rate multiply)
-    h ^= h >> 7;
-    h += h << 17;
-    return h;
+    return __umul24(t, 0x9E3779u) + __umul24(__builtin_amdgcn_ubfe(t, 24u, hi_bits), 0x85EBCBu);
 }
+__device__ __forceinline__ u32 sk_mix(u32 v) { return sk_mix_raw(v, 8u); }       // (v < 2^30)
 
 // The three bucket digits of a k-mer, functions of its minimum m-mer (so equal k-mers share them).
 //   d0 (coarse, < c0 <= 256) comes from the m-mer's HASH as the window minima carry it (hmin = hash bits 7..31 | 64 |
@@ -194,6 +195,7 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     constexpr int N = 32 + B;
     static_assert(W >= 9 && W <= 18, "window lengths of k = 23 .. 32 at m = 15");
     u32 a[N];
+    const u32 hi_bits = (u32)__popc(mmask) - 24u;          // (wave-uniform: 6 for m = 15, 2 for m = 13)
     // BATCH: bit j of `within` = this lane's m-mer j reaches across no sequence start (no mark among the m - 1 bases behind
     // its first): the marks of the 64 bases from the lane's first on, smeared over m - 1 places
     u32 within = ~0u;
@@ -214,8 +216,8 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const int q = (2 * j) >> 5, s = (2 * j) & 31;
-        const u32 v = __builtin_amdgcn_alignbit(d[q + 1], d[q], s) & mmask;        // m bases
-        a[j] = (sk_mix(v) & ~SK_GPOS_MASK) | (64u | (u32)j);                       // (one v_and_or)
+        const u32 t = __builtin_amdgcn_alignbit(d[q + 1], d[q], s);                // 16 bases: the m-mer's and more
+        a[j] = (sk_mix_raw(t, hi_bits) & ~SK_GPOS_MASK) | (64u | (u32)j);          // (one v_and_or)
         if (BATCH)
             a[j] &= (u32)((int)(within << (31 - j)) >> 31);                        // (v_bfe_i32 + v_and)
     }
@@ -905,10 +907,13 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     // position in digit d.
     __shared__ u32 gadj[ROW_STRIDE];
     __shared__ u32 gpos[SPEC ? 1 : ROW_STRIDE];
-    __shared__ u32 kcs[SPEC ? ROW_STRIDE : 1];   // SPEC: k-mers of the chunk's records per digit
     // a full tile: about half of its records at a time, in sorted order; a partial tile: the index list (16 KB of it)
     __shared__ __attribute__((aligned(16))) ull2_t stage[SK1_STAGE];
     unsigned short *idx = reinterpret_cast<unsigned short *>(stage);
+    // SPEC: while a tile is counted the stage's first words hold, per digit, records | k-mers << 32 -- ONE 64-bit LDS add
+    // per record counts both (round 3: two 32-bit adds); thread d keeps digit d's k-mers of the whole chunk in a register
+    u64 *c64 = reinterpret_cast<u64 *>(stage);
+    u32 kacc = 0;
     __shared__ u32 wtmp[SK1_NT / 64];
     __shared__ u32 split[4];                       // a full tile's halves: [0] first digit of the second, [1] its offset, [2] skew
     if (blockIdx.x >= n_chunks)
@@ -935,32 +940,58 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
     if (SPEC) {
         reg0 = spec[2 * ch.node];
         rcap = spec[2 * ch.node + 1];
-        for (u32 d = tid; d < R; d += SK1_NT)
-            kcs[d] = 0;
     }
     // after the tile's digit counts have become offsets (cnt[d]; cnt[R] = the tile's records): digit tid's slots in the
     // destination -- reserved from its global cursor, or the chunk's own running position -- as gadj[tid]
-    auto place_digits = [&]() {
+    // The reservation is ISSUED here (a returning add on a global cursor: microseconds) and FINISHED -- gadj written -- only
+    // where the tile's first write-out needs it: the staging of the first half runs while it is in flight.
+    u32 pl_base = 0;
+    bool pl_pending = false;
+    auto place_issue = [&]() {
         if ((u32)tid < R) {
             const u32 lo = cnt[tid], c = cnt[tid + 1] - lo;
-            u32 base = 0;
+            pl_base = 0;
             if (gc) {
                 if (c)
-                    base = atomicAdd(&gc[tid], c);
-                if (SPEC && c && (u64)base + c > (u64)reg0 + (u64)((u32)tid + 1) * rcap)
-                    dropped = true;
+                    pl_base = atomicAdd(&gc[tid], c);
             } else if (!SPEC) {
-                base = gpos[tid];
-                gpos[tid] = base + c;
+                pl_base = gpos[tid];
+                gpos[tid] = pl_base + c;
             }
-            gadj[tid] = base - lo;
+            gadj[tid] = 0u - lo;
+            pl_pending = true;
         }
+    };
+    auto place_finish = [&]() {
+        if (pl_pending) {
+            gadj[tid] += pl_base;                  // (SPEC: a record that falls behind its region's end is dropped, and
+            pl_pending = false;                    // reported, where it is written)
+        }
+    };
+    // the tile's digit counts (cnt[], or -- SPEC -- c64[] with the k-mers in the high words) -> exclusive offsets in cnt[],
+    // cnt[R] = the tile's records
+    auto scan_counts = [&]() {
+        u32 v = 0;
+        if ((u32)tid <= R) {
+            if (SPEC) {
+                const u64 w = c64[tid];
+                v = (u32)w;
+                kacc += (u32)(w >> 32);
+            } else {
+                v = cnt[tid];
+            }
+        }
+        block_scan_value<SK1_NT>(v, cnt, (int)R + 1, wtmp, tid);       // (R + 1 <= 513)
     };
     for (u32 t0 = 0; t0 < ch.len; t0 += SK1_TILE) {
         const u32 n_tile = ch.len - t0 < (u32)SK1_TILE ? ch.len - t0 : (u32)SK1_TILE;
         asm volatile("" : "+v"(tid));              // (thread-derived addresses recomputed per tile, not held: the kernel lives on 64 registers)
-        for (u32 d = tid; d <= R; d += SK1_NT)     // (bin R: NULL records -- unused slots of a slab sweep -- sort behind all digits)
-            cnt[d] = 0;
+        for (u32 d = tid; d <= R; d += SK1_NT) {   // (bin R: NULL records -- unused slots of a slab sweep -- sort behind all digits)
+            if (SPEC)
+                c64[d] = 0;
+            else
+                cnt[d] = 0;
+        }
         if (tid == 0) {
             split[0] = R;                          // (a tile of at most SK1_STAGE records: one half)
             split[2] = 0;
@@ -984,19 +1015,21 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const bool null = (rec[j].y >> 63) != 0;
                 const u32 dg = null ? R : (u32)(rec[j].y >> shift) & dmask;
-                atomicAdd(&cnt[dg], 1u);
-                if (SPEC && !null)
-                    atomicAdd(&kcs[dg], (u32)((rec[j].y >> 44) & 31) + 1u);
+                if (SPEC)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&c64[dg]),
+                              null ? 1ull : 1ull | ((unsigned long long)(((u32)(rec[j].y >> 44) & 31u) + 1u) << 32));
+                else
+                    atomicAdd(&cnt[dg], 1u);
             }
             __syncthreads();
-            block_scan_small<SK1_NT>(cnt, (int)R + 1, wtmp, tid);      // (R + 1 <= 513)             // cnt -> exclusive offsets; cnt[R] = the tile's records
+            scan_counts();
             const u32 n_valid = cnt[R];
             if ((u32)tid < R && cnt[tid] <= (u32)SK1_STAGE && cnt[tid + 1] > (u32)SK1_STAGE) {
                 split[0] = (u32)tid;               // (exactly one digit holds slot SK1_STAGE, if the tile has that many)
                 split[1] = cnt[tid];
                 split[2] = n_valid - cnt[tid] > (u32)SK1_STAGE ? 1u : 0u;
             }
-            place_digits();
+            place_issue();
             placed = true;
             __syncthreads();                       // (the offsets have been read: the cursors below move them)
             const u32 s_dig = split[0];
@@ -1014,6 +1047,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                         if (!(rec[j].y >> 63) && (dg >= s_dig) == (h != 0))
                             stage[atomicAdd(&cnt[dg], 1u) - lo] = rec[j];
                     }
+                    place_finish();
                     __syncthreads();
 #pragma unroll
                     for (int j = 0; j < (SK1_STAGE + SK1_NT - 1) / SK1_NT; j++) {
@@ -1027,10 +1061,13 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                         const u32 p = gadj[d] + sl;
                         if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
                             dst_all[p] = r;
+                        else
+                            dropped = true;
                     }
                     __syncthreads();
                 }
             } else {
+                place_finish();
                 for (u32 d = tid; d <= R; d += SK1_NT)
                     cnt[d] = 0;                    // (the gather ranks the tile again; its slots are reserved already)
                 __syncthreads();
@@ -1047,15 +1084,23 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const u64 m = reinterpret_cast<const u64 *>(src + t0 + i)[1];
                     const bool null = (m >> 63) != 0;
                     dig[j] = null ? R : (u32)(m >> shift) & dmask;
-                    rank[j] = atomicAdd(&cnt[dig[j]], 1u);
-                    if (SPEC && !null && !placed)
-                        atomicAdd(&kcs[dig[j]], (u32)((m >> 44) & 31) + 1u);
+                    if (SPEC && !placed) {         // (records | k-mers << 32: the returned low word is the rank)
+                        rank[j] = (u32)atomicAdd(reinterpret_cast<unsigned long long *>(&c64[dig[j]]),
+                                                 null ? 1ull : 1ull | ((unsigned long long)(((u32)(m >> 44) & 31u) + 1u) << 32));
+                    } else {
+                        rank[j] = atomicAdd(&cnt[dig[j]], 1u);
+                    }
                 }
             }
             __syncthreads();
-            block_scan_small<SK1_NT>(cnt, (int)R + 1, wtmp, tid);      // (R + 1 <= 513)             // cnt -> exclusive offsets; cnt[R] = the tile's records
-            if (!placed)
-                place_digits();
+            if (SPEC && !placed)
+                scan_counts();
+            else
+                block_scan_small<SK1_NT>(cnt, (int)R + 1, wtmp, tid);  // cnt -> exclusive offsets; cnt[R] = the tile's records
+            if (!placed) {
+                place_issue();
+                place_finish();
+            }
 #pragma unroll
             for (int j = 0; j < SK1_ITEMS; j++) {
                 const u32 i = tid + j * SK1_NT;
@@ -1072,16 +1117,16 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const u32 p = gadj[d] + sl;
                     if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
                         __builtin_nontemporal_store(r, &dst_all[p]);
+                    else
+                        dropped = true;
                 }
             }
             __syncthreads();
         }
     }
     if (SPEC) {
-        __syncthreads();
-        for (u32 d = tid; d < R; d += SK1_NT)
-            if (kcs[d])
-                atomicAdd(&kcount[nd.child_base + d], kcs[d]);
+        if ((u32)tid < R && kacc)
+            atomicAdd(&kcount[nd.child_base + (u32)tid], kacc);
         if (dropped)
             *over = 1u;
     }
