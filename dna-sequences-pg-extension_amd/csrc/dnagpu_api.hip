@@ -1489,11 +1489,21 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
     void *rec0 = nullptr;
     u64 cap = std::max<u64>(n_recs, 1);
     if (rec0_cap) {
-        u64 span = 0;
-        for (const Node &c : kids)
+        u64 span = 0, big = 0, used = 0;
+        for (const Node &c : kids) {
             span += sk_spec_span(c.len, b1);
+            big = std::max<u64>(big, c.len);
+            used += c.len ? 1 : 0;
+        }
         if (span <= 0xFFFFFFFFull)
             cap = std::max(cap, span);
+        // uneven coarse buckets (repeats): level 1's regions will come from a sampled histogram (sk_levels12), ~20 % of slack
+        // on an ordinary mid bucket: room for a third more than the records
+        if (used && (double)big * (double)used > 1.02 * (double)n_recs + 64.0 * (double)used) {
+            const u64 roomy = n_recs + n_recs / 3 + ((u64)kids.size() << b1) * 136;
+            if (roomy <= 0xFFFFFFFFull)
+                cap = std::max(cap, roomy);
+        }
         *rec0_cap = cap;
     }
     RC_TRY(pool_alloc(ctx, (size_t)cap * 16, &rec0));
@@ -1666,24 +1676,69 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
         }
         even = used == 0 || (double)big * (double)used <= 1.02 * (double)tot + 64.0 * (double)used;
     }
-    bool spec = host_lens && even && !(ctx->debug_flags & DNAGPU_DEBUG_NO_SPEC1) && span <= rec0_cap && span <= 0xFFFFFFFFull &&
-                n_coarse <= (u32)sk_max_c0() && l1.n_chunks > 0;
+    const bool can_spec = host_lens && !(ctx->debug_flags & DNAGPU_DEBUG_NO_SPEC1) && n_coarse <= (u32)sk_max_c0() && l1.n_chunks > 0;
+    bool spec = can_spec && even && span <= rec0_cap && span <= 0xFFFFFFFFull;
+    // ---- uneven coarse buckets (repeats): the regions from a SAMPLED histogram -- one piece of 1024 records in every eight
+    // of a coarse bucket's, read once (an eighth of the records: ~0.15 ms at 3 Gbase against the exact histogram's 1.0 - 1.3)
+    // -- estimate + five standard deviations + 128 slots per mid bucket, so that a heavy mid bucket gets a region of its
+    // size.  One more wait for the host (the regions' total decides the buffer); a region that overflows all the same
+    // (bursts the sample missed) falls back to the exact level like every speculative sweep.
+    u32 *rstart = nullptr, *rcapv = nullptr;
+    bool sampled = false;
+    if (can_spec && !even && !spec) {
+        std::vector<Chunk> samp;
+        const u32 slen = sk_sample1_len(), sstep = slen * sk_sample1_every();
+        for (u32 i = 0; i < n_coarse; i++)
+            for (u64 off = 0; off < host_lens[i]; off += sstep) {
+                Chunk c;
+                c.node = i;
+                c.off = (u32)off;
+                c.len = (u32)std::min<u64>(slen, host_lens[i] - off);
+                c.pad = 0;
+                samp.push_back(c);
+            }
+        Chunk *d_samp = nullptr;
+        u32 *est = nullptr, *stmp = nullptr, *tot1 = nullptr;
+        RC_TRY(ps.alloc(std::max<size_t>(samp.size(), 1), &d_samp));
+        RC_TRY(ps.alloc((size_t)l1.n_next, &est));
+        RC_TRY(ps.alloc((size_t)l1.n_next, &rcapv));
+        RC_TRY(ps.alloc((size_t)l1.n_next, &rstart));
+        RC_TRY(ps.alloc((size_t)scan_tmp_words(l1.n_next), &stmp));
+        RC_TRY(ps.alloc(1, &tot1));
+        prof_mark(ctx, "sk_sample1");
+        if (!samp.empty())
+            HIP_TRY(hipMemcpyAsync(d_samp, samp.data(), samp.size() * sizeof(Chunk), hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_sk_sampled_regions(l0.next, d_samp, (u32)samp.size(), rec0, l1.n_next, est, rcapv, rstart, stmp, tot1, st));
+        u32 total = 0;
+        RC_TRY(read_back(ctx, &total, tot1, sizeof total));      // (also: samp has been consumed)
+        // (the scan's total wraps past 2^32: regions that large are out of reach of 32-bit slots anyway -- the check below
+        // compares against rec0's room, which is below 2^32)
+        u64 chk = 0;
+        for (u32 i = 0; i < n_coarse; i++)
+            chk += host_lens[i];
+        if ((u64)total >= chk && (u64)total <= rec0_cap) {
+            span = total;
+            spec = sampled = true;
+        }
+    }
     bool moved = false;
     if (spec) {
         u32 *sp = nullptr;
         RC_TRY(ps.alloc((size_t)2 * n_coarse, &sp));
         u32 *status = d_lens + l1.n_next;         // [0] slots of all regions, [1] past 2^32, [2] overflow
         prof_mark(ctx, "sk_spec1");
-        HIP_TRY(launch_sk_spec_regions(l0.next, n_coarse, sp, status, gcur, st));
+        HIP_TRY(launch_sk_spec_regions(l0.next, n_coarse, sp, status, gcur, st, sampled ? rstart : nullptr));
         RC_TRY(pool_alloc(ctx, (size_t)std::max<u64>(std::max(n_recs, span), 1) * 16, &rec1));
         ps.ptrs.push_back(rec1);
         prof_mark(ctx, "sk_scatter1");
-        HIP_TRY(launch_sk_scatter1_spec(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, gcur, sp, kcount, status + 2, st));
-        HIP_TRY(launch_sk_spec_nodes(l0.next, l0.n_next, sp, gcur, l1.next, status + 2, st));
+        HIP_TRY(launch_sk_scatter1_spec(l0.next, l1.chunks, l1.n_chunks, rec0, rec1, gcur, sp, kcount, status + 2, st,
+                                        sampled ? rstart : nullptr, sampled ? rcapv : nullptr));
+        HIP_TRY(launch_sk_spec_nodes(l0.next, l0.n_next, sp, gcur, l1.next, status + 2, st, sampled ? rstart : nullptr,
+                                     sampled ? rcapv : nullptr));
         HIP_TRY(launch_sk_node_lens(l1.next, l1.n_next, d_lens, st));
         RC_TRY(lens_to_host(3));
         const u32 *stw = rcn.data() + l1.n_next;
-        if (stw[0] != (u32)span || stw[1] || stw[2] || (ctx->debug_flags & DNAGPU_DEBUG_SPEC1_OVERFLOW)) {
+        if ((!sampled && stw[0] != (u32)span) || (!sampled && stw[1]) || stw[2] || (ctx->debug_flags & DNAGPU_DEBUG_SPEC1_OVERFLOW)) {
             spec = false;                          // (a region overflowed, or the test flag says so: the exact level, into the same rec1)
             HIP_TRY(hipMemsetAsync(kcount, 0, (size_t)std::max<u32>(l1.n_next, 1) * sizeof(u32), st));
         } else {

@@ -208,11 +208,20 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
 // regions; 1 if they pass 2^32; the sweep's overflow flag), gcur = rows of ROW_STRIDE cursors (row = the node's first chunk).
 // The sweep counts the k-mers per mid bucket into kcount; launch_sk_spec_nodes writes the mid nodes and raises *over too.
 u64 sk_spec_span(u32 len, int bits);
-hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s);
+// Over UNEVEN coarse buckets (repeats) the regions come from a sampled histogram instead: one piece of sk_sample1_len()
+// records in every sk_sample1_every() pieces of a node's records (the host lists the pieces as chunks), rcap / rstart per mid
+// bucket (launch_sk_sampled_regions), handed to the three launchers above as rstart / rcap.
+hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s,
+                                  const u32 *rstart = nullptr);
 hipError_t launch_sk_scatter1_spec(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, u32 *gcur,
-                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s);
+                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s, const u32 *rstart = nullptr,
+                                   const u32 *rcap = nullptr);
 hipError_t launch_sk_spec_nodes(const Node *nodes, u32 n_nodes, const u32 *spec, const u32 *gcur, Node *next, u32 *over,
-                                hipStream_t s);
+                                hipStream_t s, const u32 *rstart = nullptr, const u32 *rcap = nullptr);
+u32 sk_sample1_len();
+u32 sk_sample1_every();
+hipError_t launch_sk_sampled_regions(const Node *nodes, const Chunk *samples, u32 n_samples, const void *recs, u32 n_mid, u32 *est,
+                                     u32 *rcap, u32 *rstart, u32 *scan_tmp, u32 *total, hipStream_t s);
 hipError_t launch_sk_heavy_finals(const Node *kids, u32 n, const u32 *kcount, Node *out, hipStream_t s);
 // buckets sk_count does not take, expanded to keys in record order (no host step): slices of sk_flat_slice() records
 // per bucket (n_slices[i], then after an exclusive scan slice_first[i]; slice_rec0 = first record, slice_nrec = records),

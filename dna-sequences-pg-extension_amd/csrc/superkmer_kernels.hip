@@ -883,6 +883,49 @@ __global__ __launch_bounds__(SK1_NT) void sk_hist1_kernel(const Node *__restrict
     }
 }
 
+// A SAMPLE of the same histogram, for the regions of a speculative level 1 over uneven coarse buckets (repeats): the chunks
+// are pieces of SK1_SAMPLE_LEN records, one in every SK1_SAMPLE_EVERY of a node's records (the host lists them); est[mid
+// bucket] += the records of the piece that fall into it.
+constexpr u32 SK1_SAMPLE_LEN = 1024, SK1_SAMPLE_EVERY = 8;
+u32 sk_sample1_len() { return SK1_SAMPLE_LEN; }
+u32 sk_sample1_every() { return SK1_SAMPLE_EVERY; }
+__global__ __launch_bounds__(SK1_NT) void sk_sample1_kernel(const Node *__restrict__ nodes, const Chunk *__restrict__ chunks,
+                                                            u32 n_chunks, const ull2_t *__restrict__ recs, u32 *__restrict__ est)
+{
+    __shared__ u32 h[ROW_STRIDE];
+    if (blockIdx.x >= n_chunks)
+        return;
+    const Chunk ch = chunks[blockIdx.x];
+    const Node nd = nodes[ch.node];
+    const u32 R = 1u << nd.split;
+    for (u32 d = threadIdx.x; d < R; d += SK1_NT)
+        h[d] = 0;
+    __syncthreads();
+    const u64 *hi = reinterpret_cast<const u64 *>(recs + (u64)nd.start + ch.off) + 1;
+    for (u32 i = threadIdx.x; i < ch.len; i += SK1_NT) {
+        const u64 m = __builtin_nontemporal_load(&hi[(u64)i * 2]);
+        if (!(m >> 63))
+            atomicAdd(&h[(u32)(m >> 49) & (R - 1)], 1u);
+    }
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < R; d += SK1_NT)
+        if (h[d])
+            atomicAdd(&est[nd.child_base + d], h[d]);
+}
+
+// Slots of a mid bucket whose sample held est records: the estimate, five standard deviations of it (a Poisson count
+// scaled by the sampling factor) and 128, whole 128-byte lines.  (A region's unused slots cost memory only: the mid
+// node's length is what the sweep drew.)
+__global__ __launch_bounds__(256) void sk_sampled_caps_kernel(const u32 *__restrict__ est, u32 n_mid, u32 *__restrict__ rcap)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mid)
+        return;
+    const u64 e = est[i];
+    const u64 cap = e * SK1_SAMPLE_EVERY + 5ull * SK1_SAMPLE_EVERY * sk_isqrt(e) + 128ull + 7ull;
+    rcap[i] = (u32)(cap < 0xFFFFFFF8ull ? cap : 0xFFFFFFF8ull) & ~7u;
+}
+
 // sk_scatter1: tiles of 8192 records, grouped by d1 in LDS and copied to their mid buckets in sorted order, 16 bytes per
 // lane (16 records per digit and tile on average: 256-byte runs).  Full tiles keep their records in registers between the
 // one read and the staging; the chunk's last, partial tile ranks an index list and gathers.
@@ -899,9 +942,11 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                                                              ull2_t *__restrict__ dst_all, const u32 *__restrict__ hist,
                                                              const u32 *__restrict__ tot, int shift, u32 *__restrict__ gcur,
                                                              const u32 *__restrict__ spec, u32 *__restrict__ kcount,
-                                                             u32 *__restrict__ over)
+                                                             u32 *__restrict__ over, const u32 *__restrict__ rstart,
+                                                             const u32 *__restrict__ rcapv /* or null: see sk_spec_* below */)
 {
     __shared__ u32 cnt[ROW_STRIDE];
+    __shared__ u32 glim[SPEC ? ROW_STRIDE : 1];    // SPEC: the end of digit d's region
     // gadj[d]: where the tile's sorted slot sl of digit d goes = gadj[d] + sl (the digit's base in the destination minus its
     // offset in the tile).  gpos[d] (only without global cursors: the by-d2 split of heavy buckets): the chunk's running
     // position in digit d.
@@ -935,11 +980,13 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
             gpos[d] = trow[d] + hrow[d];
     const ull2_t *src = src_all + (u64)nd.start + ch.off;
     const u32 dmask = R - 1;
-    u32 reg0 = 0, rcap = ~0u;                      // SPEC: digit d's region is [reg0 + d rcap, reg0 + (d + 1) rcap)
     bool dropped = false;
     if (SPEC) {
-        reg0 = spec[2 * ch.node];
-        rcap = spec[2 * ch.node + 1];
+        // digit d's region: [reg0 + d rcap, reg0 + (d + 1) rcap) from its parent's size, or -- over uneven coarse buckets --
+        // rstart / rcapv per mid bucket from a sampled histogram
+        const u32 reg0 = spec[2 * ch.node], rcap = spec[2 * ch.node + 1];
+        for (u32 d = tid; d < R; d += SK1_NT)
+            glim[d] = rcapv ? rstart[nd.child_base + d] + rcapv[nd.child_base + d] : reg0 + (d + 1) * rcap;
     }
     // after the tile's digit counts have become offsets (cnt[d]; cnt[R] = the tile's records): digit tid's slots in the
     // destination -- reserved from its global cursor, or the chunk's own running position -- as gadj[tid]
@@ -1059,7 +1106,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                         // (a plain store: a run's first and last cache lines are partial, and the same digit's next run --
                         // this workgroup's next tile -- completes them; kept in L2 they merge more often: 3.44 -> 3.30 ms)
                         const u32 p = gadj[d] + sl;
-                        if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
+                        if (!SPEC || p < glim[d])
                             dst_all[p] = r;
                         else
                             dropped = true;
@@ -1115,7 +1162,7 @@ __global__ __launch_bounds__(SK1_NT, 8) void sk_scatter1_kernel(const Node *__re
                     const ull2_t r = src[t0 + idx[sl]];
                     const u32 d = (u32)(r.y >> shift) & dmask;
                     const u32 p = gadj[d] + sl;
-                    if (!SPEC || (u64)p < (u64)reg0 + (u64)(d + 1) * rcap)
+                    if (!SPEC || p < glim[d])
                         __builtin_nontemporal_store(r, &dst_all[p]);
                     else
                         dropped = true;
@@ -1176,21 +1223,22 @@ __global__ __launch_bounds__(SK_MAX_C0) void sk_spec_caps_kernel(const Node *__r
 
 // the cursors at the regions' starts (a workgroup per node, a thread per child)
 __global__ __launch_bounds__(ROW_STRIDE) void sk_spec_init_kernel(const Node *__restrict__ nodes, u32 n_nodes, const u32 *__restrict__ spec,
-                                                                 u32 *__restrict__ gcur)
+                                                                 u32 *__restrict__ gcur, const u32 *__restrict__ rstart)
 {
     const u32 i = blockIdx.x, d = threadIdx.x;
     if (i >= n_nodes)
         return;
     const Node nd = nodes[i];
     if (nd.split && d < (1u << nd.split))
-        gcur[(u64)nd.chunk_base * ROW_STRIDE + d] = spec[2 * i] + d * spec[2 * i + 1];
+        gcur[(u64)nd.chunk_base * ROW_STRIDE + d] = rstart ? rstart[nd.child_base + d] : spec[2 * i] + d * spec[2 * i + 1];
 }
 
 // the mid nodes a speculative sweep leaves (what level_children makes of a histogram): start = region start, len = records
 // drawn; a cursor past its region's end raises *over
 __global__ __launch_bounds__(ROW_STRIDE) void sk_spec_nodes_kernel(const Node *__restrict__ nodes, u32 n_nodes, const u32 *__restrict__ spec,
                                                                   const u32 *__restrict__ gcur, Node *__restrict__ next,
-                                                                  u32 *__restrict__ over)
+                                                                  u32 *__restrict__ over, const u32 *__restrict__ rstart,
+                                                                  const u32 *__restrict__ rcapv)
 {
     const u32 i = blockIdx.x, d = threadIdx.x;
     if (i >= n_nodes)
@@ -1207,7 +1255,8 @@ __global__ __launch_bounds__(ROW_STRIDE) void sk_spec_nodes_kernel(const Node *_
     if (d >= (1u << nd.split))
         return;
     const int bits = (int)nd.split, rem = (int)(nd.meta & 0xff);
-    const u32 cap = spec[2 * i + 1], start = spec[2 * i] + d * cap;
+    const u32 cap = rcapv ? rcapv[nd.child_base + d] : spec[2 * i + 1];
+    const u32 start = rcapv ? rstart[nd.child_base + d] : spec[2 * i] + d * cap;
     u32 used = gcur[(u64)nd.chunk_base * ROW_STRIDE + d] - start;
     if (used > cap) {
         used = cap;
@@ -2830,38 +2879,59 @@ hipError_t launch_sk_scatter1(const Node *nodes, const Chunk *chunks, u32 n_chun
         return hipSuccess;
     hipLaunchKernelGGL(sk_scatter1_kernel<false>, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
                        reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), hist, tot, by_d2 ? 59 : 49, gcur,
-                       nullptr, nullptr, nullptr);
+                       nullptr, nullptr, nullptr, nullptr, nullptr);
     return hipGetLastError();
 }
 
 // level 1 without its histogram: regions (spec: 2 words per node; out: 3 words -- slots of all regions, 1 if past 2^32, the
 // sweep's overflow flag), cursors, the sweep (k-mers per mid bucket into kcount), the mid nodes
-hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s)
+// (rstart != null: the regions are per mid bucket -- launch_sk_sampled_regions -- and spec / out are only cleared)
+hipError_t launch_sk_spec_regions(const Node *nodes, u32 n_nodes, u32 *spec, u32 *out, u32 *gcur, hipStream_t s, const u32 *rstart)
 {
     if (n_nodes == 0 || n_nodes > (u32)SK_MAX_C0)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(sk_spec_caps_kernel, dim3(1), dim3(SK_MAX_C0), 0, s, nodes, n_nodes, spec, out);
-    hipLaunchKernelGGL(sk_spec_init_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur);
+    hipLaunchKernelGGL(sk_spec_init_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur, rstart);
     return hipGetLastError();
 }
 
+// The regions of a speculative level 1 from a SAMPLED histogram (uneven coarse buckets: repeats): est[] (zeroed here) <- the
+// records of the sample pieces per mid bucket, rcap[] <- slots per mid bucket, rstart[] <- their exclusive scan, *total <-
+// slots of all (saturating).  scan_tmp: scan_tmp_words(n_mid) words.
+hipError_t launch_sk_sampled_regions(const Node *nodes, const Chunk *samples, u32 n_samples, const void *recs, u32 n_mid, u32 *est,
+                                     u32 *rcap, u32 *rstart, u32 *scan_tmp, u32 *total, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(est, 0, (size_t)n_mid * sizeof(u32), s);
+    if (e != hipSuccess)
+        return e;
+    if (n_samples)
+        hipLaunchKernelGGL(sk_sample1_kernel, dim3(n_samples), dim3(SK1_NT), 0, s, nodes, samples, n_samples,
+                           reinterpret_cast<const ull2_t *>(recs), est);
+    hipLaunchKernelGGL(sk_sampled_caps_kernel, dim3((n_mid + 255) / 256), dim3(256), 0, s, est, n_mid, rcap);
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    return launch_scan_u32(rcap, rstart, n_mid, scan_tmp, total, s);
+}
+
 hipError_t launch_sk_scatter1_spec(const Node *nodes, const Chunk *chunks, u32 n_chunks, const void *src, void *dst, u32 *gcur,
-                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s)
+                                   const u32 *spec, u32 *kcount, u32 *over, hipStream_t s, const u32 *rstart, const u32 *rcap)
 {
     if (n_chunks == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sk_scatter1_kernel<true>, dim3(n_chunks), dim3(SK1_NT), 0, s, nodes, chunks, n_chunks,
                        reinterpret_cast<const ull2_t *>(src), reinterpret_cast<ull2_t *>(dst), nullptr, nullptr, 49, gcur, spec,
-                       kcount, over);
+                       kcount, over, rstart, rcap);
     return hipGetLastError();
 }
 
 hipError_t launch_sk_spec_nodes(const Node *nodes, u32 n_nodes, const u32 *spec, const u32 *gcur, Node *next, u32 *over,
-                                hipStream_t s)
+                                hipStream_t s, const u32 *rstart, const u32 *rcap)
 {
     if (n_nodes == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(sk_spec_nodes_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur, next, over);
+    hipLaunchKernelGGL(sk_spec_nodes_kernel, dim3(n_nodes), dim3(ROW_STRIDE), 0, s, nodes, n_nodes, spec, gcur, next, over, rstart,
+                       rcap);
     return hipGetLastError();
 }
 

@@ -699,6 +699,29 @@ def test_level1_speculative_and_exact_agree(ctx, pkg, n, k, kind):
     d.free()
 
 
+@pytest.mark.parametrize("n,k,motif", [(40_000_000, 31, 1000), (20_000_000, 27, 64), (40_000_000, 31, 100_000), (12_000_000, 21, 300)])
+def test_level1_sampled_regions_keep_repeats_speculative(ctx, pkg, n, k, motif):
+    """a motif tiled over the second half of the sequence makes the coarse buckets uneven (its records go to the few buckets of
+    its minimizers).  Round 3 sent such inputs through the exact level 1 (a histogram sweep over all records); now the
+    regions of the speculative sweep come from a histogram over an eighth of the records ("sk_sample1"): no "sk_hist1"
+    phase, the oracle's groups."""
+    words = orc.synth_words_repeat(0x5A3B1E + n, n, motif)
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False))
+    ctx.set_profiling(True)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    try:
+        h = ctx.count_kmers_unordered(d, k)
+    finally:
+        ctx.set_debug(0)
+    phases = {a for a, _ in ctx.last_phase_times()}
+    check_hist_unordered(h, ok, oc, f"sampled regions: n={n} k={k} motif={motif}")
+    h.free()
+    assert "sk_sample1" in phases and "sk_spec1" in phases and "sk_hist1" not in phases, phases
+    ctx.set_profiling(False)
+    d.free()
+
+
 @pytest.mark.parametrize("n,k,kind", [(3_000_000, 31, "random"), (5_000_001, 25, "sample misses"), (20_000_000, 27, "random"),
                                       (6_000_000, 21, "motif"), (70_000, 31, "random")])
 def test_level0_slabs_and_exact_agree(ctx, pkg, n, k, kind):
