@@ -18,6 +18,7 @@ from .binding import (  # noqa: F401
     DEBUG_NO_SPEC1,
     DEBUG_SLAB0,
     DEBUG_SLAB0_OVERFLOW,
+    DEBUG_SAMPLE1,
     DEBUG_SPEC1_OVERFLOW,
     Context,
     Dna,

@@ -29,6 +29,7 @@ DEBUG_SPEC1_OVERFLOW = 32
 DEBUG_SLAB0 = 64
 DEBUG_NO_SLAB0 = 128
 DEBUG_SLAB0_OVERFLOW = 256
+DEBUG_SAMPLE1 = 512                   # level 1: regions from a sampled histogram whatever the coarse buckets look like
 
 
 def _env_debug():

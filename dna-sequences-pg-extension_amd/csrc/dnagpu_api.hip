@@ -1499,7 +1499,8 @@ static int sk_level0(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 
             cap = std::max(cap, span);
         // uneven coarse buckets (repeats): level 1's regions will come from a sampled histogram (sk_levels12), ~20 % of slack
         // on an ordinary mid bucket: room for a third more than the records
-        if (used && (double)big * (double)used > 1.02 * (double)n_recs + 64.0 * (double)used) {
+        if ((ctx->debug_flags & DNAGPU_DEBUG_SAMPLE1) ||
+            (used && (double)big * (double)used > 1.02 * (double)n_recs + 64.0 * (double)used)) {
             const u64 roomy = n_recs + n_recs / 3 + ((u64)kids.size() << b1) * 136;
             if (roomy <= 0xFFFFFFFFull)
                 cap = std::max(cap, roomy);
@@ -1677,7 +1678,8 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
         even = used == 0 || (double)big * (double)used <= 1.02 * (double)tot + 64.0 * (double)used;
     }
     const bool can_spec = host_lens && !(ctx->debug_flags & DNAGPU_DEBUG_NO_SPEC1) && n_coarse <= (u32)sk_max_c0() && l1.n_chunks > 0;
-    bool spec = can_spec && even && span <= rec0_cap && span <= 0xFFFFFFFFull;
+    const bool force_sample = (ctx->debug_flags & DNAGPU_DEBUG_SAMPLE1) != 0;
+    bool spec = can_spec && even && !force_sample && span <= rec0_cap && span <= 0xFFFFFFFFull;
     // ---- uneven coarse buckets (repeats): the regions from a SAMPLED histogram -- one piece of 1024 records in every eight
     // of a coarse bucket's, read once (an eighth of the records: ~0.15 ms at 3 Gbase against the exact histogram's 1.0 - 1.3)
     // -- estimate + five standard deviations + 128 slots per mid bucket, so that a heavy mid bucket gets a region of its
@@ -1685,7 +1687,7 @@ static int sk_levels12(dnagpu_ctx *ctx, PoolScope &ps, const SkGeom &g, Node *co
     // (bursts the sample missed) falls back to the exact level like every speculative sweep.
     u32 *rstart = nullptr, *rcapv = nullptr;
     bool sampled = false;
-    if (can_spec && !even && !spec) {
+    if (can_spec && (!even || force_sample) && !spec) {
         std::vector<Chunk> samp;
         const u32 slen = sk_sample1_len(), sstep = slen * sk_sample1_every();
         for (u32 i = 0; i < n_coarse; i++)

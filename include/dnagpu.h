@@ -442,6 +442,10 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
 #define DNAGPU_DEBUG_SLAB0 64u
 #define DNAGPU_DEBUG_NO_SLAB0 128u
 #define DNAGPU_DEBUG_SLAB0_OVERFLOW 256u
+/* Over uneven coarse buckets (repeats; the coarse buckets only show them on long sequences) the regions of level 1's
+ * speculative sweep come from a sampled histogram -- one piece of 1024 records in every eight -- instead of the parents' sizes.
+ * DNAGPU_DEBUG_SAMPLE1 takes the sampled regions whatever the coarse buckets look like (tests on short sequences). */
+#define DNAGPU_DEBUG_SAMPLE1 512u
 int dnagpu_set_debug(dnagpu_ctx *ctx, unsigned flags);
 
 /* ---- instrumentation ------------------------------------------------------------------------

@@ -701,15 +701,16 @@ def test_level1_speculative_and_exact_agree(ctx, pkg, n, k, kind):
 
 @pytest.mark.parametrize("n,k,motif", [(40_000_000, 31, 1000), (20_000_000, 27, 64), (40_000_000, 31, 100_000), (12_000_000, 21, 300)])
 def test_level1_sampled_regions_keep_repeats_speculative(ctx, pkg, n, k, motif):
-    """a motif tiled over the second half of the sequence makes the coarse buckets uneven (its records go to the few buckets of
-    its minimizers).  Round 3 sent such inputs through the exact level 1 (a histogram sweep over all records); now the
+    """a motif tiled over the second half of a long sequence makes the coarse buckets uneven (its records go to the few buckets
+    of its minimizers).  Round 3 sent such inputs through the exact level 1 (a histogram sweep over all records); now the
     regions of the speculative sweep come from a histogram over an eighth of the records ("sk_sample1"): no "sk_hist1"
-    phase, the oracle's groups."""
+    phase, the oracle's groups.  (Sequences an oracle can count here have too few coarse buckets to show the unevenness:
+    DNAGPU_DEBUG_SAMPLE1 takes the sampled regions regardless; bench.py --motif at 3 Gbase takes them by itself.)"""
     words = orc.synth_words_repeat(0x5A3B1E + n, n, motif)
     d = ctx.upload(words, n)
     ok, oc = orc.count_keys(orc.generate_kmers(words, n, k, faithful=False))
     ctx.set_profiling(True)
-    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_SAMPLE1)
     try:
         h = ctx.count_kmers_unordered(d, k)
     finally:
