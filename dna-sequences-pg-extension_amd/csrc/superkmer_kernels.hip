@@ -493,13 +493,11 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// What building a tile's records needs of its kernel (sk_scatter0): the wave's LDS list / words / start table, the
+// What building a tile's records needs of its kernel (sk_scatter0): the wave's LDS list and words, the
 // chunk's cursors, the record buffer.
 struct SkBuild {
-    u64 *wl;                // list entries: key << 32 | start row << 16 | end row; start = 0xFFFF: the run started in an
-                            // earlier lane (ns_tab)
+    u64 *wl;                // list entries (see sk_build)
     const u64 *wsh;         // the tile's packed words (word 0 = the one holding its first base)
-    const u32 *ns_tab;      // per lane: start row of the run that is open at the lane's first row
     u32 *gpos;              // per coarse digit: the chunk's next slot
     const u32 *gend;        // ... and the end of its slots (slab mode; else all ones)
     ull2_t *recs;
@@ -511,9 +509,14 @@ struct SkBuild {
 // hash and position (key = that minimum) -- they carry the minimum m-mer's offset, and the m-mer's value (for d1 / d2) is
 // cut from the tile's words there; else (the walk by the m-mer's value: key = that value) SK_REC_MULTI.  Returns true if
 // a record found its digit's slots used up (slab mode).
+// mode 0: entries key << 32 | start row << 16 | end row, key = the m-mer's value (the walk by value);
+// mode 1: the same, key = the minimum itself (the exact walk in four passes);
+// mode 2: entries key << 32 | end row IN ROW ORDER, key = the minimum itself (a plain tile): a record starts where its
+//         predecessor ended.
 template <bool BATCH>
-__device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, bool exact)
+__device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, int mode)
 {
+    const bool exact = mode != 0;
     const int dbg = b.dbg;
     (void)dbg;
     bool dropped = false;
@@ -535,7 +538,8 @@ __device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, bool exact)
         const SkDigits dg = sk_digits(hmin, v, b.c0n, b.b1mask);
         const u32 gslot = atomicAdd(&b.gpos[dg.d0], 1u);
         u32 start = ((u32)en >> 16) & 0xFFFFu;
-        start = start == 0xFFFFu ? b.ns_tab[end_row >> 5] : start;
+        if (mode == 2)
+            start = e ? ((u32)b.wl[e - 1] & 0xFFFFu) + 1u : 0u;
         const u32 len = end_row - start + 1u;
         // the record's 108 payload bits from bit 2 q of the tile's words: six dwords, four funnel shifts
         const u32 q = start + b.fo;                // first base of the run, relative to the tile's first word
@@ -603,7 +607,7 @@ __device__ __forceinline__ bool sk_scatter0_walk(SkFront<W> &f, const SkBuild &b
             continue;
         }
         sk_wave_fence();                           // list and words written by other lanes of this wave
-        if (sk_build<BATCH>(bx, wrun, !BYV))
+        if (sk_build<BATCH>(bx, wrun, BYV ? 0 : 1))
             dropped = true;
         sk_wave_fence();                           // wsh / list are rewritten by the next pass / tile
     }
@@ -640,7 +644,6 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
     __shared__ u32 gend[SK_MAX_C0], gbeg[SK_MAX_C0];
     __shared__ u64 wsh_all[SK_NT / 64][66];       // per wave: the tile's packed words -- record payloads are cut from here
     __shared__ u64 list_all[SK_NT / 64][SKW_LIST + 64];   // per wave: the tile's records (see below); + an entry per lane for writes that list nothing
-    __shared__ u32 ns_all[SK_NT / 64][64];         // per wave and lane: start row of the run that is open at the lane's first row
     if (blockIdx.x >= n_chunks)
         return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -663,12 +666,10 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
     }
     __syncthreads();
     u64 *wsh = wsh_all[wave], *wl = list_all[wave];
-    u32 *ns_tab = ns_all[wave];
     bool dropped = false;
     SkBuild bx;
     bx.wl = wl;
     bx.wsh = wsh;
-    bx.ns_tab = ns_tab;
     bx.gpos = gpos;
     bx.gend = gend;
     bx.recs = recs;
@@ -690,36 +691,37 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         // list (very short runs: low-complexity sequence) is redone in four passes of eight row positions each, which always
         // fit (8 x 63 records).
         bx.fo = fo;
-        auto build = [&](u32 wrun, bool exact) {
-            if (sk_build<BATCH>(bx, wrun, exact))
+        auto build = [&](u32 wrun, int mode) {
+            if (sk_build<BATCH>(bx, wrun, mode))
                 dropped = true;
         };
         if (f.plain) {
-            // records = natural runs: no branch per row -- a lane whose row ends nothing (and lane 63, which owns no rows)
-            // writes to an entry of its own behind the list; so does whatever would overflow the list (the tile is then
-            // redone in four passes by the general walk).  A lane does not know where the run that is open at its first
-            // row started: such an entry carries 0xFFFF, and the start -- the last start of the lanes before (a max scan
-            // over the lanes' last starts, one LDS word per lane) -- is looked up when the record is built.
+            // records = natural runs, listed IN ROW ORDER: every lane counts the records that end in its rows (a compare and
+            // an add-with-carry per row), one wave scan gives it its first list slot, and a second sweep over its rows writes
+            // the entries -- key << 32 | end row -- there; a row that ends nothing (and lane 63, which owns no rows) writes to
+            // an entry of its own behind the list.  A record's first row is its predecessor's last + 1 (sk_build), so no
+            // start is tracked here.  (Round 3 ranked the ends of every row position across the wave -- ballot, two mbcnt,
+            // a popcount -- and tracked every lane's open run: ten vector and three scalar operations per row, seven now.)
             const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
-            const u32 dummy = (u32)SKW_LIST + (u32)lane;
-            const u32 r0 = (u32)lane * 32;
-            u32 start = (lane == 0 || f.hm[0] != f.prev_last) ? r0 : 0xFFFFu;
-            u32 wrun = 0;                          // wave-uniform: records listed
+            u32 cnt = 0;
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
-                const u32 row = r0 + (u32)j;
-                const bool end = nxt != f.hm[j] && lane < 63;
-                const u64 b = __ballot(end);
-                const u32 pos = wrun + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));
-                wl[end ? min(pos, (u32)SKW_LIST + 63u) : dummy] = ((u64)f.hm[j] << 32) | (u64)((start << 16) | row);
-                start = end ? row + 1 : start;
-                wrun += (u32)__popcll(b);
-            }
-            ns_tab[lane] = wave_prev(wave_incl_max(start == 0xFFFFu ? 0u : start));
-            sk_wave_fence();                       // list, words and starts written by other lanes of this wave
+            for (int j = 0; j < 32; j++)
+                cnt += ((j < 31 ? f.hm[j + 1] : nf) != f.hm[j]) ? 1u : 0u;
+            cnt = lane < 63 ? cnt : 0u;
+            const u32 incl = wave_incl_scan(cnt);
+            const u32 wrun = (u32)__builtin_amdgcn_readlane((int)incl, 63);   // wave-uniform: records of the tile
             if (wrun <= (u32)SKW_LIST) {
-                build(wrun, true);
+                u32 p = incl - cnt;
+                const u32 dummy = (u32)SKW_LIST + (u32)lane;
+                const u32 r0 = (u32)lane * 32;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const bool end = ((j < 31 ? f.hm[j + 1] : nf) != f.hm[j]) && lane < 63;
+                    wl[end ? p : dummy] = ((u64)f.hm[j] << 32) | (u64)(r0 + (u32)j);
+                    p += end ? 1u : 0u;
+                }
+                sk_wave_fence();                   // list and words written by other lanes of this wave
+                build(wrun, 2);
                 sk_wave_fence();                   // wsh / list are rewritten by the next tile
                 continue;
             }
