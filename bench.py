@@ -136,7 +136,7 @@ def main():
     n_bases, k, seed = cfg["n_bases"], cfg["k"], cfg["seed"]
     n_kmers = n_bases - k + 1
     global SK_RUN
-    SK_RUN = (max(k - (15 if k >= 23 else 13) + 1, 1) + 1) / 2.0
+    SK_RUN = (max(k - (15 if k >= 23 else 13 if k >= 21 else 12) + 1, 1) + 1) / 2.0
     is_filter = cfg["kind"] == "filter"
     if is_filter and world > 1:
         raise SystemExit("config 5 is a single-GPU workload (BASELINE.json)")
@@ -440,7 +440,7 @@ def main_one_process(args):
     n_kmers = n_bases - k + 1
     W = args.gpus
     global SK_RUN
-    SK_RUN = (max(k - (15 if k >= 23 else 13) + 1, 1) + 1) / 2.0
+    SK_RUN = (max(k - (15 if k >= 23 else 13 if k >= 21 else 12) + 1, 1) + 1) / 2.0
 
     from __graft_entry__ import load_package
     pkg = load_package()

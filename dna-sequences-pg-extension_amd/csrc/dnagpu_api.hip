@@ -2225,7 +2225,8 @@ static bool sk_is_default(u64 n, int k)
         return false;
     if (k >= SK_MIN_K)
         return true;
-    return (k == 22 && n <= ((u64)1 << 31)) || (k == 21 && n <= ((u64)1 << 29));
+    // (k = 20: 12-base minimizers keep the final buckets even up to ~2^28 rows)
+    return (k == 22 && n <= ((u64)1 << 31)) || (k == 21 && n <= ((u64)1 << 29)) || (k == 20 && n <= ((u64)1 << 28));
 }
 static int count_core(dnagpu_ctx *ctx, const dnagpu_dna *dna, u64 first, u64 n, int k, u64 *keys_in,
                       dnagpu_hist **out, int fixed_bits = 0, u64 fixed_prefix = 0, int owner = 0, int n_owners = 1,

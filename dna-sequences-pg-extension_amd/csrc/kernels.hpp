@@ -180,7 +180,7 @@ hipError_t launch_batch_keys(const u64 *words, u64 n_words, const u32 *marks, u6
 // mid buckets into key nodes.  k in [sk_min_k(), 32]; c0n = coarse buckets, b1bits = bits of d1, r0bits = split
 // bits of the root (2^r0bits >= c0n); records are 16 bytes each.
 int sk_min_k();
-int sk_minimizer_len(int k);          // m: 15 for k >= 23, 13 for k = 21, 22
+int sk_minimizer_len(int k);          // m: 15 for k >= 23, 13 for k = 21, 22, 12 for k = 20
 int sk_tile_rows();
 int sk_max_c0();          // most coarse buckets the level-0 sweeps support
 // aux: the histogram sweep adds its chunks' counts into ONE row aux[0 .. 2^r0bits) instead of hist rows (a sampled

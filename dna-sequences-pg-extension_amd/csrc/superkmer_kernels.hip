@@ -349,7 +349,7 @@ __device__ __forceinline__ void sk_front_open(SkFront<W> &f, const Keys &key, u3
     u32 kprev = key.prev_last;
     const u32 k0 = key(0);
     u32 kcur = k0;
-#pragma unroll 1
+#pragma unroll 8
     for (int j = 0; j < 32; j++) {
         const bool brk = j == 0 ? (lane == 0 || kcur != kprev) : kcur != kprev;
         if (brk)
@@ -376,7 +376,7 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, const Keys &
     asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
     u32 kprev = 0, kcur = key(0);
-#pragma unroll 1
+#pragma unroll 8
     for (int j = 0; j < 32; j++) {
         const u32 nxt = j < 31 ? key(j + 1) : key.next_first;
         bool end = false;
@@ -393,8 +393,10 @@ __device__ __forceinline__ void sk_records_all(const SkFront<W> &f, const Keys &
 }
 
 // walks the thread's rows in order and calls emit(j, end_row, len, hmin, key) for every record that ENDS in them (j = the
-// row's index among the thread's 32).  (These walks run out of line -- sk_hist0_general, sk_scatter0_general -- with the
-// SkFront in memory: their loops over the rows stay rolled, a dozen registers instead of a hundred.)
+// row's index among the thread's 32).  (These walks run out of line -- sk_hist0_general, sk_scatter0_general -- over a memory
+// copy of the SkFront.  Unrolled eight rows at a time: fully rolled, every row waits for its minimum to come back from scratch
+// memory -- a sequence that is half poly-A took 31 ms instead of 24 --; fully unrolled, the walks' registers cost the kernels
+// around them theirs.)
 template <int W, typename Keys, typename Emit>
 __device__ __forceinline__ void sk_records(const SkFront<W> &f, const Keys &key, u32 lmax, Emit &&emit)
 {
@@ -402,7 +404,7 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, const Keys &key,
     asm volatile("" : "+v"(r0));                  // (see sk_front_open)
     u32 c = f.c0;
     u32 kprev = 0, kcur = key(0);
-#pragma unroll 1
+#pragma unroll 8
     for (int j = 0; j < 32; j++) {
         const u32 nxt = j < 31 ? key(j + 1) : key.next_first;
         if ((u32)j < f.n_valid) {
@@ -2081,7 +2083,7 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
     vtab[tid + SKQ_NT] = ~(u64)0;
     if (tid < 2)
         shared_flag[tid] = 0;
-    const u32 mlen = k >= 23 ? 15u : 13u;          // sk_minimizer_len
+    const u32 mlen = k >= 23 ? 15u : (k >= 21 ? 13u : 12u);   // sk_minimizer_len
     const u32 vmask = (1u << (2u * mlen)) - 1u, kmm = (u32)k - mlen;
     const u32 flank = kmm / 2u < 8u ? kmm / 2u : 8u, fmask = (1u << (2u * flank)) - 1u;
     const u32 hmask = (u32)(kmer_mask(k) >> 32);   // (k >= 21: the low dword of a key is whole)
@@ -2813,11 +2815,13 @@ static void launch_front(bool scatter, u32 n_chunks, hipStream_t s, const Chunk 
                            lmax, mmask, c0n, b1mask, r0n, hist, aux, marks, n_mark_words);
 }
 
+// (k = 20, round 4: 12 bases, a window of 9 -- 4^12 / 5 ~ 3 M effective minimizer values: even final buckets up to ~2^28 rows,
+// which is where the engine is the default for it; longer sequences of 20-mers stay on the tree)
 // The minimizer's length m: 15 for k >= 23 (windows of 9 .. 18 m-mers), 13 for k = 21 and 22 (windows of 9 and 10: runs of
 // 5 - 5.5 k-mers, 3 bytes per k-mer; 4^13 / 9 ~ 7 M effective minimizer values keep the final buckets even up to 2^32
 // rows).  A function of k alone, so every rank of a sharded count cuts the same records.
-int sk_min_k() { return 21; }
-int sk_minimizer_len(int k) { return k >= 23 ? 15 : 13; }
+int sk_min_k() { return 20; }
+int sk_minimizer_len(int k) { return k >= 23 ? 15 : (k >= 21 ? 13 : 12); }
 
 hipError_t launch_sk_level0(bool scatter, const Chunk *chunks, u32 n_chunks, const u64 *words, u64 n_words, u64 first, int k,
                             u32 c0n, u32 b1bits, u32 r0bits, u32 *hist, const u32 *tot, void *recs, hipStream_t s, u32 *aux,

@@ -178,8 +178,8 @@ typedef struct dnagpu_hist dnagpu_hist;
 int dnagpu_count_kmers(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k,
                        uint64_t first, uint64_t count, dnagpu_hist **out);
 /* The same groups when the caller does not need them in key order -- PostgreSQL's own GROUP BY order is
- * unspecified (test.sql:95-104), so this is what the SQL entry point calls.  Long k-mers (k >= 21) of long
- * sequences (2^25 rows or more; k = 21 and 22: where that is the faster engine, up to 2^29 / 2^31 rows) are then
+ * unspecified (test.sql:95-104), so this is what the SQL entry point calls.  Long k-mers (k >= 20) of long
+ * sequences (2^25 rows or more; k = 20, 21 and 22: where that is the faster engine, up to 2^28 / 2^29 / 2^31 rows) are then
  * partitioned as super-k-mers (runs of consecutive k-mers sharing a minimizer, 16 bytes per
  * ~9 k-mers) instead of 8-byte keys: less than a third of the partition traffic.  dnagpu_hist_download and
  * dnagpu_hist_sorted_view then serve the groups bucket by bucket (keys ascending inside a bucket only);
@@ -284,7 +284,7 @@ int dnagpu_buffer_upload(dnagpu_ctx *ctx, void *dev_ptr, const void *host, uint6
  * bucket to its owner (1.8 bytes per k-mer instead of 8; the caller's all-to-all), and counts what it receives
  * (dnagpu_count_records): equal k-mers meet because they share the bucket.  global_rows = the rows of the whole
  * count: every rank must pass the same value (it fixes the bucket geometry, and the digits are part of the
- * records).  k in [21, 32] (minimizers of 15 bases for k >= 23, of 13 for k = 21 and 22). */
+ * records).  k in [20, 32] (minimizers of 15 bases for k >= 23, of 13 for k = 21 and 22, of 12 for k = 20). */
 typedef struct dnagpu_records dnagpu_records;
 /* number of coarse buckets of a count of global_rows rows (0: arguments out of range) */
 int dnagpu_sk_buckets(const dnagpu_ctx *ctx, uint64_t global_rows, int k);
@@ -353,7 +353,7 @@ void dnagpu_multi_dna_free(dnagpu_multi *m, dnagpu_multi_dna *d);
  * result, the other ranks' histograms are empty -- the same concatenation property. */
 int dnagpu_count_multi(dnagpu_multi *m, const dnagpu_multi_dna *dna, int k, uint64_t first, uint64_t count,
                        dnagpu_hist **hists);
-/* The same groups with no order promise (PostgreSQL's GROUP BY makes none, test.sql:95-104), for long k-mers (k >= 21;
+/* The same groups with no order promise (PostgreSQL's GROUP BY makes none, test.sql:95-104), for long k-mers (k >= 20;
  * shorter ones go through dnagpu_count_multi): the record exchange above from one process.  Nothing is gathered:
  * rank r cuts the super-k-mer records of the rows that start in its own chunk, the owner of a coarse bucket pulls the
  * bucket's pieces from every rank (peer copies of 16-byte records, 1.8 B per k-mer at k = 31) and counts them.
@@ -417,7 +417,7 @@ int dnagpu_kmer_match(dnagpu_ctx *ctx, const uint64_t *keys, uint64_t n, int k,
  * work buffer before writing it sees garbage in every run, not only in a warm context. */
 #define DNAGPU_DEBUG_POISON_POOL 1u
 /* DNAGPU_DEBUG_FORCE_SUPERKMER: dnagpu_count_kmers_unordered takes the super-k-mer engine for every k it supports
- * (21..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
+ * (20..32) and every sequence length, not only where it is the faster one (tests of its shorter windows). */
 #define DNAGPU_DEBUG_FORCE_SUPERKMER 2u
 /* DNAGPU_DEBUG_HEAVY_EXPAND: the super-k-mer engine expands its heavy mid buckets to keys for the ordinary levels (the
  * older path, still what records received from other ranks take when most of them are heavy) instead of splitting

@@ -629,7 +629,8 @@ def check_hist_unordered(hist, ok, oc, what):
                                        (9_000_000, 31, 12345), (17_000_029, 31, 0), (40_000_000, 29, 1),
                                        (3_000_000, 24, 0), (3_000_000, 25, 5), (3_000_000, 26, 0), (3_000_000, 28, 31),
                                        (3_000_000, 30, 0), (70_000, 31, 3), (1_000, 32, 0),
-                                       (5_000_011, 21, 0), (4_000_000, 22, 9), (40_000_000, 21, 1), (1_000, 21, 0), (70_000, 22, 3)])
+                                       (5_000_011, 21, 0), (4_000_000, 22, 9), (40_000_000, 21, 1), (1_000, 21, 0), (70_000, 22, 3),
+                                       (5_000_011, 20, 0), (40_000_000, 20, 7), (1_000, 20, 0)])
 def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     """dnagpu_count_kmers_unordered on sequences long enough for super-k-mer partitioning: the groups are the
     oracle's (sorted on the host for the comparison); a window that does not start on a word boundary"""
@@ -647,7 +648,8 @@ def test_count_unordered_superkmers(ctx, pkg, n, k, first):
     check_hist_unordered(h, ok, oc, f"unordered n={n} k={k} first={first}")
     h.free()
     rows = len(keys)                                 # the default choice of engine (dnagpu_api.hip: sk_is_default)
-    if rows >= (1 << 25) and (k >= 23 or (k == 22 and rows <= (1 << 31)) or (k == 21 and rows <= (1 << 29))):
+    if rows >= (1 << 25) and (k >= 23 or (k == 22 and rows <= (1 << 31)) or (k == 21 and rows <= (1 << 29)) or
+                              (k == 20 and rows <= (1 << 28))):
         h = ctx.count_kmers_unordered(d, k, first=first)
         assert not h.is_sorted
         assert h.summary() == orc.hist_summary(ok, oc)
@@ -1149,10 +1151,10 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
     words, starts = table_of_sequences(0xBA7C4 + n_seqs, n_seqs, lo, hi)
     n = int(starts[-1])
     d = ctx.upload(words, n)
-    for k in (31, 21, 32, 25, 10, 3):
+    for k in (31, 21, 32, 25, 20, 10, 3):
         ok, oc = orc.count_keys(orc.generate_kmers_table(words, starts, k))
         for forced in (True, False):
-            if forced and k < 21:
+            if forced and k < 20:
                 continue
             ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER | pkg.DEBUG_SLAB0 if forced else 0)
             try:

@@ -1,5 +1,5 @@
 """Randomised parity soak of the unordered count (super-k-mer engine, all its paths) against the oracle: random lengths,
-k in 21..32, repeat motifs, planted heavy stretches, windows, and the debug flags that steer the paths (engine forced;
+k in 20..32, repeat motifs, planted heavy stretches, windows, and the debug flags that steer the paths (engine forced;
 heavy mid buckets expanded instead of split; level 1 speculative / exact / forced fall-back).  Usage: python tools/fuzz_unordered.py [cases] [max_n] [seed]"""
 import os
 import sys
@@ -20,7 +20,7 @@ bad = 0
 with pkg.Context(0) as ctx:
     for c in range(cases):
         n = int(rng.integers(64, max_n)) if rng.random() < 0.8 else int(rng.integers(64, 50_000))
-        k = int(rng.integers(21, 33))
+        k = int(rng.integers(20, 33))
         seed = int(rng.integers(0, 2**31))
         motif = int(rng.choice([0, 0, 1, 2, 3, 7, 31, 64, 1000, 50_000]))
         if motif and motif * 2 < n:
