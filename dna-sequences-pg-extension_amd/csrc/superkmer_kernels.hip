@@ -424,10 +424,12 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, const Keys &key,
     }
 }
 
-// The general walk of sk_hist0, OUT OF LINE: non-plain tiles are rare (none on random sequence), and inlined the walk's
-// registers were the kernel's (85 -> 128 VGPRs with spills: one wave less per SIMD for every tile).
+// The general walk of sk_hist0 over a MEMORY copy of the front, its loops over the rows unrolled eight at a time: non-plain
+// tiles are rare (none on random sequence), and fully unrolled over the front's registers the walk's registers were the
+// kernel's (85 -> 128 VGPRs with spills: one wave less per SIMD for every tile).  (As a function of its own -- tried -- every
+// call saves and restores the callee-saved registers through scratch: a sequence that is half poly-A took 31 ms.)
 template <int W, bool BATCH>
-__device__ __noinline__ void sk_hist0_general(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 lmax, u32 mmask,
+__device__ __forceinline__ void sk_hist0_general(SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 lmax, u32 mmask,
                                               u32 c0n, u32 *h /* LDS */)
 {
     SkKeys<W, BATCH, true> vk(f, words, n_words, pos0, mmask);
@@ -576,7 +578,7 @@ __device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, int mode)
     return dropped;
 }
 
-// The general walk of sk_scatter0, OUT OF LINE (see sk_hist0_general): a partial tile or long runs of one hash (by_value:
+// The general walk of sk_scatter0 (over a memory copy of the front: see sk_hist0_general): a partial tile or long runs of one hash (by_value:
 // records = runs of one m-mer VALUE, cut every lmax rows), or a plain tile whose list overflowed (!by_value: the SAME records
 // as its branch-free walk -- sk_hist0 counted those -- in four passes of eight row positions each, which always fit).
 template <int W, bool BATCH, bool BYV>
@@ -616,7 +618,7 @@ __device__ __forceinline__ bool sk_scatter0_walk(SkFront<W> &f, const SkBuild &b
     return dropped;
 }
 template <int W, bool BATCH>
-__device__ __noinline__ bool sk_scatter0_general(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
+__device__ __forceinline__ bool sk_scatter0_general(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
                                                  u64 tile_pos, u32 lmax, bool by_value)
 {
     return by_value ? sk_scatter0_walk<W, BATCH, true>(f, bx, words, n_words, tile_pos, lmax)
