@@ -44,6 +44,7 @@ constexpr int SKW_ROWS = 63 * 32;                // rows (k-mers) a WAVE tile em
 constexpr int SK_TILE_ROWS = (SK_NT / 64) * SKW_ROWS;   // one round of the workgroup's waves (chunks are cut at multiples of it)
 constexpr int SK_MAX_C0 = 256;                   // most coarse buckets (digits of level 0): 2^32 rows need 195
 constexpr int SKW_LIST = 512;                    // records of a wave tile listed in LDS (a tile of random bases has ~225)
+constexpr int SK_PLAIN_MAX = 384;                // a full tile of at most this many (hash, position) runs is cut into exactly those
 
 int sk_tile_rows() { return SK_TILE_ROWS; }
 int sk_max_c0() { return SK_MAX_C0; }
@@ -246,28 +247,16 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     // neighbours' boundary minima
     f.next_first = wave_next(f.hm[0]) + 32u;
     f.prev_last = wave_prev(f.hm[31]) - 32u;
-    // A PLAIN tile: full, and no run of equal minimum HASHES longer than 20 rows.  Its records are the runs of equal
-    // minima, hash AND position (cut at the tile's end): one m-mer occurrence stays the minimum of at most W <= 18
-    // windows, so such a record never outgrows lmax, and all its k-mers have their leftmost minimum m-mer at one place.
-    // On random sequence every tile is plain.  Longer runs of one hash need a repeated m-mer (low-complexity sequence):
-    // there the position moves on row after row, and the tile goes through the general walk, which cuts by the minimum
-    // m-mer's VALUE and every lmax rows (SK_REC_MULTI records).  Test on every fourth row of the tile: six such samples in a row span 21
-    // rows -- more than any run of W rows covers -- so six equal samples in a row send the tile through the general
-    // walk, and nothing else does.  (Shorter stretches of a repeated m-mer stay in plain tiles as a few short records.)
-    u32 smp[13];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        smp[i] = f.hm[4 * i] >> 6;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        smp[8 + i] = (i == 0 ? f.next_first : wave_next(f.hm[4 * i])) >> 6;
-    bool long_run = false;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        long_run = long_run || (smp[i] == smp[i + 1] && smp[i + 1] == smp[i + 2] && smp[i + 2] == smp[i + 3] &&
-                                smp[i + 3] == smp[i + 4] && smp[i + 4] == smp[i + 5] &&
-                                (!BATCH || smp[i] != 0u));   // (the k - 1 rows across a sequence start are no repeat)
-    f.plain = n_rows == (u32)SKW_ROWS && __ballot(long_run && lane < 63) == 0;
+    // A tile may be PLAIN if it is full.  Its records are then the runs of equal minima, hash AND position (cut at the
+    // tile's end): one m-mer occurrence stays the minimum of at most W <= 18 windows, so such a record never outgrows lmax,
+    // and all its k-mers have their leftmost minimum m-mer at one place.  On random sequence a tile has ~225 of them.
+    // Where one m-mer repeats (low-complexity sequence) its leftmost occurrence moves on row after row: a record per row.
+    // A short stretch of that costs a few short records and nothing else; a tile that is MOSTLY that -- more than
+    // SK_PLAIN_MAX records, which its callers count -- goes through the general walk instead, which cuts by the m-mer's
+    // VALUE and every lmax rows (SK_REC_MULTI records).  (Round 3 and the first half of round 4 tested for a run of one
+    // hash over 21 rows on every fourth row -- 55 operations per lane and tile -- and sent every tile with ONE such stretch
+    // through the general walk: on real sequence that is every tenth tile, all of its records SK_REC_MULTI.)
+    f.plain = n_rows == (u32)SKW_ROWS;
 }
 
 // bits [sh, sh + 64) of hi:lo, sh in 0 .. 127
@@ -464,12 +453,19 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
         const u32 n_rows = ch.len - t0 < (u32)SKW_ROWS ? ch.len - t0 : (u32)SKW_ROWS;
         SkFront<W> f;
         sk_front<W, BATCH>(f, words, n_words, first + ch.off + t0, n_rows, lmax, mmask, nullptr, marks, n_mark_words);
-        if (f.plain) {
+        bool plain = f.plain;
+        const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
+        if (plain) {                               // (the tile's records if it is cut as a plain tile: sk_scatter0 counts the same)
+            u32 cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                cnt += ((j < 31 ? f.hm[j + 1] : nf) != f.hm[j]) ? 1u : 0u;
+            plain = wave_sum(lane < 63 ? cnt : 0u) <= (u32)SK_PLAIN_MAX;
+        }
+        if (plain) {
             // a record ends at every row whose successor has another minimum -- hash or position -- (lane 62's last row: the
             // tile's end).  No branch per row: a lane whose row ends nothing adds to a word of its own behind the histogram.
-            // (sk_scatter0 cuts the same records whether its list of them overflows or not.)
             if (lane < 63) {
-                const u32 nf = lane == 62 ? ~f.hm[31] : f.next_first;
 #pragma unroll
                 for (int j = 0; j < 32; j++) {
                     const u32 nxt = j < 31 ? f.hm[j + 1] : nf;
@@ -480,7 +476,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
                 }
             }
         } else {
-            SkFront<W> fm = f;                     // (a copy in memory for the out-of-line walk: f itself stays in registers)
+            SkFront<W> fm = f;                     // (a copy in memory for the walk: f itself stays in registers)
             sk_hist0_general<W, BATCH>(fm, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
         }
     }
@@ -578,9 +574,10 @@ __device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, int mode)
     return dropped;
 }
 
-// The general walk of sk_scatter0 (over a memory copy of the front: see sk_hist0_general): a partial tile or long runs of one hash (by_value:
-// records = runs of one m-mer VALUE, cut every lmax rows), or a plain tile whose list overflowed (!by_value: the SAME records
-// as its branch-free walk -- sk_hist0 counted those -- in four passes of eight row positions each, which always fit).
+// The general walk of sk_scatter0 (over a memory copy of the front: see sk_hist0_general): a partial tile, or a full one of
+// more than SK_PLAIN_MAX (hash, position) runs (low-complexity sequence) -- records = runs of one m-mer VALUE, cut every lmax
+// rows (BYV; the walk by the minima themselves, !BYV, is kept for reference: nothing calls it now).  A list that overflows
+// in one pass is redone in four passes of eight row positions each, which always fit.
 template <int W, bool BATCH, bool BYV>
 __device__ __forceinline__ bool sk_scatter0_walk(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
                                                  u64 tile_pos, u32 lmax)
@@ -619,10 +616,9 @@ __device__ __forceinline__ bool sk_scatter0_walk(SkFront<W> &f, const SkBuild &b
 }
 template <int W, bool BATCH>
 __device__ __forceinline__ bool sk_scatter0_general(SkFront<W> &f, const SkBuild &bx, const u64 *__restrict__ words, u64 n_words,
-                                                 u64 tile_pos, u32 lmax, bool by_value)
+                                                    u64 tile_pos, u32 lmax)
 {
-    return by_value ? sk_scatter0_walk<W, BATCH, true>(f, bx, words, n_words, tile_pos, lmax)
-                    : sk_scatter0_walk<W, BATCH, false>(f, bx, words, n_words, tile_pos, lmax);
+    return sk_scatter0_walk<W, BATCH, true>(f, bx, words, n_words, tile_pos, lmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,7 +710,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             cnt = lane < 63 ? cnt : 0u;
             const u32 incl = wave_incl_scan(cnt);
             const u32 wrun = (u32)__builtin_amdgcn_readlane((int)incl, 63);   // wave-uniform: records of the tile
-            if (wrun <= (u32)SKW_LIST) {
+            if (wrun <= (u32)SK_PLAIN_MAX) {
                 u32 p = incl - cnt;
                 const u32 dummy = (u32)SKW_LIST + (u32)lane;
                 const u32 r0 = (u32)lane * 32;
@@ -730,11 +726,11 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
                 continue;
             }
         }
-        // the general walk (out of line): a partial tile or long runs of one hash, or a plain tile whose list overflowed
+        // the general walk: a partial tile, or one of too many (hash, position) runs
         {
             SkFront<W> fm = f;                     // (a copy in memory for it: f itself stays in registers)
             const SkBuild bm = bx;
-            if (sk_scatter0_general<W, BATCH>(fm, bm, words, n_words, tile_pos, lmax, !f.plain))
+            if (sk_scatter0_general<W, BATCH>(fm, bm, words, n_words, tile_pos, lmax))
                 dropped = true;
         }
     }
