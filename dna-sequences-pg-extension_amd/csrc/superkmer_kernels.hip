@@ -43,8 +43,10 @@ constexpr int SK_NT = 256;                       // threads of a front-end workg
 constexpr int SKW_ROWS = 63 * 32;                // rows (k-mers) a WAVE tile emits records for: lane 63 only supplies hashes
 constexpr int SK_TILE_ROWS = (SK_NT / 64) * SKW_ROWS;   // one round of the workgroup's waves (chunks are cut at multiples of it)
 constexpr int SK_MAX_C0 = 256;                   // most coarse buckets (digits of level 0): 2^32 rows need 195
-constexpr int SKW_LIST = 512;                    // records of a wave tile listed in LDS (a tile of random bases has ~225)
-constexpr int SK_PLAIN_MAX = 384;                // a full tile of at most this many (hash, position) runs is cut into exactly those
+constexpr int SKW_LIST = 768;                    // records of a wave tile listed in LDS (a tile of random bases has ~225 at k = 31, ~400 at k = 21)
+// a full tile of at most this many (hash, position) runs is cut into exactly those: 1.7 times what random sequence gives
+// (2016 rows in runs of (w + 1) / 2)
+__host__ __device__ constexpr u32 sk_plain_max(int w) { return (u32)(2 * SKW_ROWS * 17 / (10 * (w + 1))) < (u32)SKW_LIST ? (u32)(2 * SKW_ROWS * 17 / (10 * (w + 1))) : (u32)SKW_LIST; }
 
 int sk_tile_rows() { return SK_TILE_ROWS; }
 int sk_max_c0() { return SK_MAX_C0; }
@@ -252,7 +254,7 @@ __device__ __forceinline__ void sk_front(SkFront<W> &f, const u64 *__restrict__ 
     // and all its k-mers have their leftmost minimum m-mer at one place.  On random sequence a tile has ~225 of them.
     // Where one m-mer repeats (low-complexity sequence) its leftmost occurrence moves on row after row: a record per row.
     // A short stretch of that costs a few short records and nothing else; a tile that is MOSTLY that -- more than
-    // SK_PLAIN_MAX records, which its callers count -- goes through the general walk instead, which cuts by the m-mer's
+    // sk_plain_max(W) records, which its callers count -- goes through the general walk instead, which cuts by the m-mer's
     // VALUE and every lmax rows (SK_REC_MULTI records).  (Round 3 and the first half of round 4 tested for a run of one
     // hash over 21 rows on every fourth row -- 55 operations per lane and tile -- and sent every tile with ONE such stretch
     // through the general walk: on real sequence that is every tenth tile, all of its records SK_REC_MULTI.)
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
 #pragma unroll
             for (int j = 0; j < 32; j++)
                 cnt += ((j < 31 ? f.hm[j + 1] : nf) != f.hm[j]) ? 1u : 0u;
-            plain = wave_sum(lane < 63 ? cnt : 0u) <= (u32)SK_PLAIN_MAX;
+            plain = wave_sum(lane < 63 ? cnt : 0u) <= sk_plain_max(W);
         }
         if (plain) {
             // a record ends at every row whose successor has another minimum -- hash or position -- (lane 62's last row: the
@@ -575,7 +577,7 @@ __device__ __forceinline__ bool sk_build(const SkBuild &b, u32 wrun, int mode)
 }
 
 // The general walk of sk_scatter0 (over a memory copy of the front: see sk_hist0_general): a partial tile, or a full one of
-// more than SK_PLAIN_MAX (hash, position) runs (low-complexity sequence) -- records = runs of one m-mer VALUE, cut every lmax
+// more than sk_plain_max(W) (hash, position) runs (low-complexity sequence) -- records = runs of one m-mer VALUE, cut every lmax
 // rows (BYV; the walk by the minima themselves, !BYV, is kept for reference: nothing calls it now).  A list that overflows
 // in one pass is redone in four passes of eight row positions each, which always fit.
 template <int W, bool BATCH, bool BYV>
@@ -710,10 +712,11 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
             cnt = lane < 63 ? cnt : 0u;
             const u32 incl = wave_incl_scan(cnt);
             const u32 wrun = (u32)__builtin_amdgcn_readlane((int)incl, 63);   // wave-uniform: records of the tile
-            if (wrun <= (u32)SK_PLAIN_MAX) {
+            if (wrun <= sk_plain_max(W)) {
                 u32 p = incl - cnt;
                 const u32 dummy = (u32)SKW_LIST + (u32)lane;
-                const u32 r0 = (u32)lane * 32;
+                u32 r0 = (u32)lane * 32;
+                asm volatile("" : "+v"(r0));       // (else the 32 row numbers are held across the tile loop: see sk_front_open)
 #pragma unroll
                 for (int j = 0; j < 32; j++) {
                     const bool end = ((j < 31 ? f.hm[j + 1] : nf) != f.hm[j]) && lane < 63;
