@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--k", type=int, default=None, help="override the config's k")
     ap.add_argument("--motif", type=int, default=0,
                     help="repeat-rich variant (SURVEY.md 8(d)): tile the first MOTIF bases over the second half")
+    ap.add_argument("--genome-like", action="store_true",
+                    help="count configs, single GPU: instead of uniform random bases a genome-LIKE sequence generated on the host "
+                         "(tools/genome_like.py: an Alu-like family, exact segmental duplications, microsatellites) and uploaded")
     ap.add_argument("--pattern", type=str, default=None, help="config 5: the qkmer pattern (length k)")
     ap.add_argument("--engine", choices=["auto", "tree"], default="auto",
                     help="count configs: auto = dnagpu_count_kmers_unordered (GROUP BY semantics: group order "
@@ -207,7 +210,13 @@ def main():
                 phases_acc.setdefault(name, []).append(ms)
             h.free()
     elif world == 1:
-        dna = ctx.synth(seed, n_bases, motif_len=args.motif)
+        if args.genome_like:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import genome_like
+            dna = ctx.upload(genome_like.packed_words(n_bases, seed), n_bases)
+            extra["input"] = "genome-like (tools/genome_like.py: Alu-like copies 10 %, segmental duplications 2 %, microsatellites 1 %)"
+        else:
+            dna = ctx.synth(seed, n_bases, motif_len=args.motif)
 
         count_fn = ctx.count_kmers if args.engine == "tree" else ctx.count_kmers_unordered
 
@@ -283,7 +292,7 @@ def main():
             parts_ = torch.tensor([[v >> 32, v & 0xFFFFFFFF] for v in mine], dtype=torch.int64, device=red_dev)
             dist.all_reduce(parts_)
             mine = [((int(hi) << 32) + int(lo)) & 0xFFFFFFFFFFFFFFFF for hi, lo in parts_.tolist()]
-        digest = digest_check(args.config, n_bases, k, seed, args.motif, mine, rows=n_kmers)
+        digest = digest_check(args.config if not args.genome_like else 0, n_bases, k, seed, args.motif, mine, rows=n_kmers)
 
     if rank == 0 and world == 1 and not is_filter and not sorted_result[0]:
         extra["sorted_view_ms"] = None
