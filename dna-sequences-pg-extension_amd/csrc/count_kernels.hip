@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const Node *__restrict_
 }
 
 // split width of one node (0 = not split at this level); n_over = the level's oversize nodes (levels >= 2)
-__device__ __forceinline__ int plan_bits(const Node &nd, int level, u32 n_over, int l1_cap)
+// skew_from: the first level whose oversize nodes are skew (2; one more if the levels start from the super-k-mer engine's
+// bucket nodes, whose first split is by size like a root's)
+__device__ __forceinline__ int plan_bits(const Node &nd, int level, u32 n_over, int l1_cap, int skew_from)
 {
     const int rem = (int)(nd.meta & 0xff);
     int bits = 0;
@@ -133,7 +135,7 @@ __device__ __forceinline__ int plan_bits(const Node &nd, int level, u32 n_over, 
         if (level == 0) {
             if (want > MAX_SPLIT_BITS)
                 want = (want + 1) / 2;          // two balanced levels
-        } else if (level >= 2) {
+        } else if (level >= skew_from) {
             // An oversize node this deep is skew, not chance (planned leaves sit >= 4.5 sigma under the capacity):
             // typically heavy k-mers plus a leaf's worth of others.  Fan out wider than the size asks for, so
             // that a heavy key is soon alone (and its node recognised as constant by level_hist) -- as wide as
@@ -179,13 +181,14 @@ __device__ __forceinline__ void plan_account(const Node &nd, int bits, LevelCoun
 
 __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32 n_nodes, int level,
                                                    u32 chunk_len, u32 *__restrict__ outc,
-                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap)
+                                                   u32 *__restrict__ nch, LevelCounters *__restrict__ ctr, int l1_cap,
+                                                   int skew_from)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes)
         return;
     const Node nd = nodes[i];
-    const int bits = plan_bits(nd, level, level >= 2 ? ctr->n_over : 0u, l1_cap);
+    const int bits = plan_bits(nd, level, level >= 2 ? ctr->n_over : 0u, l1_cap, skew_from);
     plan_account(nd, bits, ctr);
     nodes[i].split = (u32)bits;
     outc[i] = bits ? (1u << bits) : 1u;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void plan_kernel(Node *__restrict__ nodes, u32
 // the plan and two three-kernel scans (~45 us of launches per level; a count at 100 Mbase has three such levels).
 __global__ __launch_bounds__(1024) void plan_small_kernel(Node *__restrict__ nodes, u32 n_nodes, int level, u32 chunk_len,
                                                           u32 *__restrict__ outc, u32 *__restrict__ nch,
-                                                          LevelCounters *__restrict__ ctr, int l1_cap)
+                                                          LevelCounters *__restrict__ ctr, int l1_cap, int skew_from)
 {
     __shared__ LevelCounters lc;
     __shared__ u32 sa[1024], sb[1024], wtmp[16];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(1024) void plan_small_kernel(Node *__restrict__ nod
     }
     int bits = 0;
     if (i < n_nodes) {
-        bits = plan_bits(nd, level, lc.n_over, l1_cap);
+        bits = plan_bits(nd, level, lc.n_over, l1_cap, skew_from);
         plan_account(nd, bits, &lc);
         nodes[i].split = (u32)bits;
     }
@@ -251,7 +254,7 @@ static int plan_l1_cap()
 }
 
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
-                       LevelCounters *ctr, hipStream_t s)
+                       LevelCounters *ctr, hipStream_t s, int skew_from)
 {
     if (n_nodes == 0)
         return hipSuccess;
@@ -259,22 +262,23 @@ hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *
     if (level >= 2)
         hipLaunchKernelGGL(plan_count_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, ctr);
     hipLaunchKernelGGL(plan_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, s, nodes, n_nodes, level,
-                       chunk_len, outc, nch, ctr, l1_cap);
+                       chunk_len, outc, nch, ctr, l1_cap, skew_from);
     return hipGetLastError();
 }
 
 // The whole planning step of a level: counters zeroed, every node planned, outc / nch turned into exclusive scans with
 // their totals in ctr->n_next / ctr->n_chunks.  scan_tmp: scan_tmp_words(n_nodes) words.
 hipError_t launch_plan_level(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch, u32 *scan_tmp,
-                             LevelCounters *ctr, hipStream_t s)
+                             LevelCounters *ctr, hipStream_t s, int skew_from)
 {
     if (n_nodes > 0 && n_nodes <= 1024) {
         const int l1_cap = plan_l1_cap();
-        hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, s, nodes, n_nodes, level, chunk_len, outc, nch, ctr, l1_cap);
+        hipLaunchKernelGGL(plan_small_kernel, dim3(1), dim3(1024), 0, s, nodes, n_nodes, level, chunk_len, outc, nch, ctr, l1_cap,
+                           skew_from);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(ctr, 0, sizeof(LevelCounters), s);
-    if (e == hipSuccess) e = launch_plan(nodes, n_nodes, level, chunk_len, outc, nch, ctr, s);
+    if (e == hipSuccess) e = launch_plan(nodes, n_nodes, level, chunk_len, outc, nch, ctr, s, skew_from);
     if (e == hipSuccess) e = launch_scan_u32(outc, outc, n_nodes, scan_tmp, &ctr->n_next, s);
     if (e == hipSuccess) e = launch_scan_u32(nch, nch, n_nodes, scan_tmp, &ctr->n_chunks, s);
     return e;

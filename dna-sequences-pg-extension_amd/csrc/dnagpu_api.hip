@@ -1273,7 +1273,7 @@ static int run_tree(dnagpu_ctx *ctx, PoolScope &ps, const dnagpu_dna *dna, u64 f
         RC_TRY(ps.alloc((size_t)scan_tmp_words(n_nodes), &scan_tmp));
         RC_TRY(ps.alloc(1, &ctr));
         HIP_TRY(launch_plan_level(cur, n_nodes, (force_bits > 0 && level == 0) ? -force_bits : level, chunk_len, outc, nch,
-                                  scan_tmp, ctr, st));
+                                  scan_tmp, ctr, st, init_nodes ? start_level + 1 : 2));
         LevelCounters hc;
         RC_TRY(read_back(ctx, &hc, ctr, sizeof hc));
         if (hc.n_split == 0) {
@@ -2149,6 +2149,11 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
         }
         RC_TRY(run_tree(ctx, ps, nullptr, 0, tree_keys, k, kbuf, 0, &tr, 0, 0, true, 0, ~0u, 0, knodes, n_tree, 2));
     }
+#ifdef DNAGPU_STAMPS
+    fprintf(stderr, "[sk select] n_fin %u small %u big %u (k-mers of big %u) over %u (keys %llu) heavy %u (keys %llu) tree nodes %u tiny %u small %u big %u\n",
+            n_fin, n_small, n_big, ht[3], n_over, (unsigned long long)over_keys, n_heavy, (unsigned long long)heavy.total, tr.n_nodes,
+            tr.n_tiny, tr.n_small, tr.n_big);
+#endif
     const u32 n_segs = n_fin + tr.n_nodes;
     RC_TRY(ps.alloc((size_t)n_segs, &seg_off));
     RC_TRY(ps.alloc((size_t)n_segs, &seg_cnt));
@@ -2162,6 +2167,7 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
         prof_mark(ctx, "leaves");
         HIP_TRY(launch_leaves(tr.nodes, tr.n_nodes, tr.n_tiny, tr.n_small, tr.n_big, tr.buf0, tr.buf1, cursor, seg_off + n_fin,
                               seg_cnt + n_fin, ok, oc, flags, ltmp, cls_list, st, true, small_keys));
+        HIP_TRY(launch_sk_unmix(ok, small_keys, cursor, tr.n_keys, k, st));      // (sk_expand_flat wrote key_mix(key))
     }
     prof_mark(ctx, "sk_count");
     u32 *left = nullptr;

@@ -102,10 +102,11 @@ struct LevelCounters {  // read back by the host once per level
 };
 
 hipError_t launch_plan(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch,
-                       LevelCounters *ctr, hipStream_t s);
+                       LevelCounters *ctr, hipStream_t s, int skew_from = 2);
 // plan + both scans + counters of a level (one launch for levels of at most 1024 nodes)
+// skew_from: the first level at which an oversize node means skew and is fanned out wider than its size asks
 hipError_t launch_plan_level(Node *nodes, u32 n_nodes, int level, u32 chunk_len, u32 *outc, u32 *nch, u32 *scan_tmp,
-                             LevelCounters *ctr, hipStream_t s);
+                             LevelCounters *ctr, hipStream_t s, int skew_from = 2);
 hipError_t launch_fill_chunks(const Node *nodes, u32 n_nodes, u32 chunk_len, const u32 *child_base,
                               const u32 *chunk_base, Node *nodes_rw, Chunk *chunks, hipStream_t s);
 // src_dna != 0: the (single) node being split is the root over the packed sequence; flt_lo/flt_span:
@@ -235,6 +236,8 @@ hipError_t launch_sk_slice_kmers(const void *recs, const u32 *slice_rec0, const 
                                  hipStream_t s);
 hipError_t launch_sk_slice_nodes(const Node *buckets, u32 nb, const u32 *slice_first, const u32 *slice_koff, u32 n_slices,
                                  const u32 *total_keys, u32 key_base, int k, bool check_kmers, Node *out, u64 *n_bad, hipStream_t s);
+// keys[first .. *end): key_unmix (the groups of the tree over the expansion's mixed keys; at most max_groups of them)
+hipError_t launch_sk_unmix(u64 *keys, u64 first, const u64 *end, u64 max_groups, int k, hipStream_t s);
 hipError_t launch_sk_expand_flat(const void *recs, const u32 *slice_rec0, const u32 *slice_nrec, const u32 *slice_koff, u32 key_base,
                                  u32 n_slices, int k, u64 *keys, hipStream_t s);
 // every mid bucket's records regrouped by d2 from src into the same range of dst; out_nodes[16 i + j] = final bucket:

@@ -23,6 +23,31 @@ __device__ __forceinline__ u64 funnel(u64 lo, u64 hi, unsigned sh)
     return (lo >> sh) | ((hi << 1) << (63u - sh));
 }
 
+// A bijection of the 2k-bit keys and its inverse (k in 20..32): the keys of one minimizer's bucket are near-copies of each
+// other (the same m-mer at the same offset, a repeat family's consensus around it), and a most-significant-digit split of
+// such keys separates nothing for levels on end.  The super-k-mer engine's expansion therefore hands the levels
+// key_mix(key) -- equal keys stay equal, everything else is spread evenly over the 2k bits -- and the groups are turned
+// back (key_unmix) once the leaves have written them: an unordered histogram has no order to keep.
+// (x ^= x >> k is its own inverse on 2k bits; the multipliers are odd, so they have inverses modulo any power of two)
+__host__ __device__ __forceinline__ u64 key_mix(u64 x, int k, u64 mask)
+{
+    x ^= x >> k;
+    x = (x * 0x9E3779B97F4A7C15ull) & mask;
+    x ^= x >> k;
+    x = (x * 0xD6E8FEB86659FD93ull) & mask;
+    x ^= x >> k;
+    return x;
+}
+__host__ __device__ __forceinline__ u64 key_unmix(u64 x, int k, u64 mask)
+{
+    x ^= x >> k;
+    x = (x * 0xCFEE444D8B59A89Bull) & mask;
+    x ^= x >> k;
+    x = (x * 0xF1DE83E19937733Dull) & mask;
+    x ^= x >> k;
+    return x;
+}
+
 // key of the k-mer starting at base `pos` (masked); words[n_words] is never read
 __device__ __forceinline__ u64 key_at(const u64 *__restrict__ words, u64 n_words, u64 pos, u64 mask)
 {

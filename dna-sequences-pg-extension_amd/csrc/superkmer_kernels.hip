@@ -1398,13 +1398,32 @@ __global__ __launch_bounds__(256) void sk_expand_flat_kernel(const ull2_t *__res
         const u32 o = inc - len;
         const u64 hi = rec.y & (((u64)1 << 44) - 1);
         for (u32 j = 0; j < len; j++)
-            stage[o + j] = funnel(rec.x, hi, 2 * j) & kmask;
+            stage[o + j] = key_mix(funnel(rec.x, hi, 2 * j) & kmask, k, kmask);   // (see key_mix: the levels split mixed keys)
         sk_wave_fence();
         for (u32 s = lane; s < n_keys; s += 64)
             __builtin_nontemporal_store(stage[s], &keys[out + s]);
         sk_wave_fence();
         out += n_keys;
     }
+}
+
+// the groups of the expansion's tree, keys[first .. *end), back from key_mix
+__global__ __launch_bounds__(256) void sk_unmix_kernel(u64 *__restrict__ keys, u64 first, const unsigned long long *__restrict__ end,
+                                                       int k)
+{
+    const u64 e = *end, mask = kmer_mask(k);
+    for (u64 i = first + (u64)blockIdx.x * 256 + threadIdx.x; i < e; i += (u64)gridDim.x * 256)
+        keys[i] = key_unmix(keys[i], k, mask);
+}
+
+hipError_t launch_sk_unmix(u64 *keys, u64 first, const u64 *end, u64 max_groups, int k, hipStream_t s)
+{
+    if (max_groups == 0)
+        return hipSuccess;
+    const u64 g = (max_groups + 1023) / 1024;
+    hipLaunchKernelGGL(sk_unmix_kernel, dim3((u32)(g < 4096 ? g : 4096)), dim3(256), 0, s, keys, first,
+                       reinterpret_cast<const unsigned long long *>(end), k);
+    return hipGetLastError();
 }
 
 // heavy mid buckets leave the record path: out[j] = mids[idx[j]] with child_base = its k-mers; the list entry is emptied

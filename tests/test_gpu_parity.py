@@ -767,8 +767,18 @@ def test_level0_slabs_and_exact_agree(ctx, pkg, n, k, kind):
     d.free()
 
 
+def genome_like_words(n, seed=0x6E0):
+    """tools/genome_like.py: an Alu-like family of diverged copies, exact segmental duplications, microsatellites"""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import genome_like
+    return genome_like.packed_words(n, seed)
+
+
 @pytest.mark.parametrize("kind", ["motif1000", "motif37", "motif100000", "polyA", "half-polyA", "quarter-polyA", "AT",
-                                  "small-polyA", "small-AT"])
+                                  "small-polyA", "small-AT", "genome-like"])
 @pytest.mark.parametrize("k", [31, 21])
 def test_count_unordered_repeats(ctx, pkg, kind, k):
     """repeat-rich and low-complexity inputs through the unordered entry: heavy buckets are split further by the
@@ -790,6 +800,10 @@ def test_count_unordered_repeats(ctx, pkg, kind, k):
     elif kind == "quarter-polyA":
         words = orc.synth_words(93, n)
         words[: len(words) // 4] = 0
+    elif kind == "genome-like":
+        # near-copies: a minimizer's bucket holds thousands of k-mers that differ in a base or two -- the expansion's
+        # tree splits them as key_mix(key) and turns the groups back (sk_unmix)
+        words = genome_like_words(n)
     else:
         words = orc.synth_words(92, n)
         words[: len(words) // 2] = 0
@@ -928,6 +942,25 @@ def test_count_kmers_owned(ctx, n_owners):
         assert_same(np.concatenate(all_k), fk, "owners concatenated = global keys")
         assert_same(np.concatenate(all_c), fc, "owners concatenated = global counts")
         d.free()
+
+
+@pytest.mark.parametrize("k", [32, 26, 20])
+def test_count_unordered_near_copies_every_key_width(ctx, pkg, k):
+    """the expansion's keys travel mixed (key_mix is a bijection of the 2k-bit keys: 64 bits at k = 32, where the mixed
+    all-ones key is counted beside the leaves' tables) -- a repeat family's near-copies, the engine forced so that its
+    buckets are oversize at this size"""
+    n = 4_000_000
+    words = genome_like_words(n, 0x77 + k)
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_kmers(words, n, k)
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    try:
+        h = ctx.count_kmers_unordered(d, k)
+        check_hist_unordered(h, ok, oc, f"near copies k={k}")
+        h.free()
+    finally:
+        ctx.set_debug(0)
+    d.free()
 
 
 @pytest.mark.parametrize("motif", [1000, 64, 1, 100000])

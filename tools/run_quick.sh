@@ -5,7 +5,7 @@ TAG=${1:-quick}; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python3 -m pytest tests -q -m gpu -x -k "test_count_unordered_superkmers or level0_slabs or level1_spec or level1_sampled or repeat" > $O/pytest.log 2>&1; rc=$?
+timeout -k 10 300 python3 -m pytest tests -q -m gpu -x -k "test_count_unordered_superkmers or level0_slabs or level1_spec or level1_sampled or repeat or near_copies" > $O/pytest.log 2>&1; rc=$?
 echo "rc=$rc" >> $O/pytest.log; tail -3 $O/pytest.log
 [ $rc -eq 0 ] || exit 1
 timeout -k 10 200 python3 tools/fuzz_unordered.py 120 > $O/fuzz.log 2>&1; rc=$?; tail -1 $O/fuzz.log
