@@ -2173,6 +2173,13 @@ static int count_sk_tail(dnagpu_ctx *ctx, PoolScope &ps, void *recs, Node *fin, 
     u32 *left = nullptr;
     RC_TRY(ps.alloc((size_t)2 * n_small + 1, &left));
     HIP_TRY(launch_sk_count(fin, list_small, off_small, n_small, recs, k, cursor + 2, seg_off, seg_cnt, ok, oc, left, st));
+#ifdef DNAGPU_STAMPS
+    {
+        u32 nl = 0;
+        RC_TRY(read_back(ctx, &nl, left + 2 * (size_t)n_small, 4));
+        fprintf(stderr, "[sk count] %u small buckets, %u left to sk_count by sk_count_clean\n", n_small, nl);
+    }
+#endif
     prof_mark(ctx, "end");
     u64 fin_ctr[3] = {0, 0, 0};
     RC_TRY(read_back(ctx, fin_ctr, cursor, 24));

@@ -2069,8 +2069,12 @@ __device__ __forceinline__ bool sk_records_share_kmer(const ull2_t A, u32 a, u32
 // and one of the two halves equal: two XORs per passed entry; the few pairs that pass (4^-F per side) take the exact test.
 // A bucket in which no two records share a k-mer holds every k-mer ONCE: its k-mers are cut from the records and leave as
 // (key, 1) groups, one k-mer per thread and round, 8 + 4 bytes per lane to consecutive addresses -- no k-mer hash, no probe,
-// no table.  Every other bucket (copies: a handful per million on random sequence; repeats; a SK_REC_MULTI record of a
-// low-complexity stretch) is appended to a list that sk_count takes afterwards, exact as before.
+// no table.  A bucket in which SOME records share k-mers (a stretch that occurs again elsewhere: a handful of buckets per
+// million on random sequence, nearly every bucket of a real genome) keeps that path for all its other records and counts
+// only the sharing records' k-mers, up to SKQ_DIRTY_MAX of them, in the record table's slots once the records are done
+// with them (a k-mer of a record that shares nothing has no copy; a copy of a sharing record's k-mer lies in a record that
+// shares with it).  What is left -- a SK_REC_MULTI record of a low-complexity stretch, more copies than that -- is
+// appended to a list that sk_count takes afterwards, exact as before.
 //   Why: round 3's sk_count spent 265 vector + 200 scalar instructions per wave and bucket, a third of them probing the
 //   k-mer table for k-mers that never had a copy, the rest bookkeeping around sixteen waves (quads, claim prefixes, keys
 //   kept a bucket long, four ballot rounds of stores).  This kernel has eight waves per bucket, no table to clear, and
@@ -2079,6 +2083,7 @@ constexpr int SKQ_NT = 512;
 static_assert(SKQ_NT == SKC_MAXREC, "a thread per record");
 constexpr int SKQ_KMERS = 4096;                  // sk_count_cap(): most k-mers of a small bucket
 constexpr int SKQ_VSLOTS = 1024;                 // record table (at most 512 entries)
+constexpr int SKQ_DIRTY_MAX = 640;               // most k-mers of sharing records that are counted in those slots
 
 __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
                                                                    const u32 *__restrict__ list_off, u32 n_list,
@@ -2093,16 +2098,25 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
     __shared__ __attribute__((aligned(16))) ull2_t lrec[SKC_MAXREC];
     __shared__ __attribute__((aligned(16))) u64 vtab[SKQ_VSLOTS];
     __shared__ unsigned short own[SKQ_KMERS];      // k-mer of the bucket -> record | position in it << 9
-    __shared__ u32 wk[WAVES];
-    __shared__ u32 shared_flag[2];                 // by bucket parity: the bucket goes to sk_count
+    __shared__ u32 wk[WAVES], wk2[WAVES];
+    __shared__ u32 shared_flag[2], multi_flag[2];  // by bucket parity: two records share a k-mer; a SK_REC_MULTI record
+    __shared__ u32 dcnt2[SKQ_VSLOTS / 2];          // (buckets with copies) the counts beside vtab's k-mer keys, 16 bits each
+    __shared__ unsigned short cpos[SKC_MAXREC];    // ... a record's first output slot, or 0xFFFF: its k-mers are counted
+    __shared__ unsigned char rdb[SKC_MAXREC];      // ... the record shares a k-mer with another
+    __shared__ u32 d_ones;
+    unsigned short *dcnt = reinterpret_cast<unsigned short *>(dcnt2);
     int tid = threadIdx.x;
     u32 lq = blockIdx.x;
     if (lq >= n_list)
         return;
     vtab[tid] = ~(u64)0;
     vtab[tid + SKQ_NT] = ~(u64)0;
+    dcnt2[tid] = 0;
+    rdb[tid] = 0;
     if (tid < 2)
-        shared_flag[tid] = 0;
+        shared_flag[tid] = multi_flag[tid] = 0;
+    if (tid == 0)
+        d_ones = 0;
     const u32 mlen = k >= 23 ? 15u : (k >= 21 ? 13u : 12u);   // sk_minimizer_len
     const u32 vmask = (1u << (2u * mlen)) - 1u, kmm = (u32)k - mlen;
     const u32 flank = kmm / 2u < 8u ? kmm / 2u : 8u, fmask = (1u << (2u * flank)) - 1u;
@@ -2147,7 +2161,7 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                     own[k0 + j] = (unsigned short)((u32)tid | (j << 9));
             if (SK_DBG(256)) {
             } else if (yh & (1u << (SK_REC_MULTI_BIT - 32))) {
-                shared_flag[par] = 1u;             // (nothing is known about where this record's m-mer is)
+                multi_flag[par] = 1u;              // (nothing is known about where this record's m-mer is)
             } else {
                 const u32 p0 = (u32)me.x, p1 = (u32)(me.x >> 32), p2 = (u32)me.y, p3 = yh & 3u;
                 const u32 a = (yh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK;
@@ -2175,8 +2189,11 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                         const ull2_t ot = lrec[oid];
                         const u32 oyh = (u32)(ot.y >> 32);
                         if (sk_records_share_kmer(me, a, nba, ot, (oyh >> (SK_POS_SHIFT - 32)) & SK_POS_MASK,
-                                                  ((oyh >> 12) & 31u) + (u32)k, mlen, kmm))
+                                                  ((oyh >> 12) & 31u) + (u32)k, mlen, kmm)) {
                             shared_flag[par] = 1u;
+                            rdb[tid] = 1;
+                            rdb[oid] = 1;
+                        }
                     }
                     slot = (slot + 1u) & (u32)(SKQ_VSLOTS - 1);
                 }
@@ -2186,28 +2203,107 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
         __syncthreads();                           // (2) owners and the verdict complete
         if (vslot != ~0u)
             vtab[vslot] = ~(u64)0;                 // (the table is clean again for the next bucket)
-        if (shared_flag[par]) {
-            if (tid == 0) {                        // two records may share a k-mer: the bucket is sk_count's
-                const u32 d = atomicAdd(n_left, 1u);
-                left_list[d] = li;
-                left_off[d] = off;
+        u64 *ok = out_keys + off;
+        u32 *oc = out_counts + off;
+        auto key_of = [&](u32 i) -> u64 {
+            const u32 e = own[i];
+            const ull2_t r = lrec[e & 511u];
+            const u32 p0 = (u32)r.x, p1 = (u32)(r.x >> 32), p2 = (u32)r.y, p3 = (u32)(r.y >> 32) & 3u;
+            const u32 sh = 2u * (e >> 9);          // (<= 2 (w - 1) = 34)
+            const bool up = sh >= 32u;
+            const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2;
+            const u32 kl = __builtin_amdgcn_alignbit(a1, a0, sh), kh = __builtin_amdgcn_alignbit(a2, a1, sh) & hmask;
+            return ((u64)kh << 32) | kl;
+        };
+        const u32 flag = shared_flag[par] | (multi_flag[par] << 1);
+        if (flag) {
+            // ---- some records share k-mers with others (a copy of a stretch elsewhere: the rule on real genomes, a handful
+            // of buckets per million on random sequence).  Only THOSE records' k-mers can have copies: every other record's
+            // k-mers leave as (key, 1) as below, compacted by a prefix over the records; the sharing records' k-mers -- up to
+            // SKQ_DIRTY_MAX of them -- are counted in the record table's slots (empty again by now) and leave behind them.
+            // A bucket with a SK_REC_MULTI record or with more k-mers to count goes to sk_count's list.
+            const bool dirty = have && rdb[tid] != 0;
+            rdb[tid] = 0;
+            const u32 pk = dirty ? (len << 16) : len;
+            const u32 pinc = wave_incl_scan(pk);
+            if (lane == 63)
+                wk2[wave] = pinc;
+            __syncthreads();                       // (A) wk2; every slot of vtab is empty again
+            u32 pbase = 0, ptot = 0;
+            sk_wave_prefix16(wk2, WAVES, wave, lane, pbase, ptot);
+            const u32 n_clean = ptot & 0xFFFFu, n_dirty = ptot >> 16;
+            if ((flag & 2u) || n_dirty > (u32)SKQ_DIRTY_MAX) {
+                if (tid == 0) {
+                    const u32 d = atomicAdd(n_left, 1u);
+                    left_list[d] = li;
+                    left_off[d] = off;
+                }
+            } else {
+                cpos[tid] = dirty ? (unsigned short)0xFFFFu : (unsigned short)((pbase + pinc - pk) & 0xFFFFu);
+                __syncthreads();                   // (B) cpos
+                for (u32 i = (u32)tid; i < n_km; i += SKQ_NT) {
+                    const u32 e = own[i];
+                    const u32 c = cpos[e & 511u];
+                    const u64 key = key_of(i);
+                    if (c != 0xFFFFu) {
+                        __builtin_nontemporal_store(key, &ok[c + (e >> 9)]);
+                        __builtin_nontemporal_store(1u, &oc[c + (e >> 9)]);
+                    } else if (key == ~(u64)0) {
+                        atomicAdd(&d_ones, 1u);    // (the 32-base k-mer GG..G: the empty slot's value)
+                    } else {
+                        u32 slot = ((((u32)key ^ (u32)(key >> 32)) * 0x9E3779B1u) >> 22) & (u32)(SKQ_VSLOTS - 1);
+                        for (;;) {
+                            const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&vtab[slot]), ~0ull, (unsigned long long)key);
+                            if (old == ~(u64)0 || old == key)
+                                break;
+                            slot = (slot + 1u) & (u32)(SKQ_VSLOTS - 1);
+                        }
+                        atomicAdd(&dcnt2[slot >> 1], 1u << ((slot & 1u) * 16u));
+                    }
+                }
+                __syncthreads();                   // (C) the table complete
+                const u32 c0 = dcnt[tid], c1 = dcnt[tid + SKQ_NT], ones = d_ones;
+                const u64 b0 = __ballot(c0 != 0), b1 = __ballot(c1 != 0);
+                if (lane == 0)
+                    wk2[wave] = (u32)__popcll(b0) + (u32)__popcll(b1);
+                __syncthreads();                   // (D)
+                u32 before = 0, D = 0;
+                sk_wave_prefix16(wk2, WAVES, wave, lane, before, D);
+                const u64 lt = ((u64)1 << lane) - 1;
+                u64 *dk = ok + n_clean;
+                u32 *dc = oc + n_clean;
+                if (c0) {
+                    const u32 r = before + (u32)__popcll(b0 & lt);
+                    dk[r] = vtab[tid];
+                    dc[r] = c0;
+                    vtab[tid] = ~(u64)0;
+                    dcnt[tid] = 0;
+                }
+                if (c1) {
+                    const u32 r = before + (u32)__popcll(b0) + (u32)__popcll(b1 & lt);
+                    dk[r] = vtab[tid + SKQ_NT];
+                    dc[r] = c1;
+                    vtab[tid + SKQ_NT] = ~(u64)0;
+                    dcnt[tid + SKQ_NT] = 0;
+                }
+                const u32 groups = n_clean + D + (ones ? 1u : 0u);
+                for (u32 i = groups + (u32)tid; i < n_km; i += SKQ_NT)
+                    oc[i] = 0;                     // (the rest of the bucket's range is padding: count 0)
+                if (tid == 0) {
+                    if (ones) {
+                        dk[D] = ~(u64)0;
+                        dc[D] = ones;
+                        d_ones = 0;
+                    }
+                    seg_off[li] = off;
+                    seg_cnt[li] = groups;
+                    my_groups += groups;
+                }
             }
         } else {
             // ---- every k-mer of the bucket is the only one of its kind: (key, 1) groups, k-mer i at slot off + i
             // Two k-mers per thread and round: 16 bytes of keys and 8 of counts per lane, nontemporal (a plain store stream
             // tops out near 3.3 TB/s on this chip); the pairs start on an even output slot.
-            u64 *ok = out_keys + off;
-            u32 *oc = out_counts + off;
-            auto key_of = [&](u32 i) -> u64 {
-                const u32 e = own[i];
-                const ull2_t r = lrec[e & 511u];
-                const u32 p0 = (u32)r.x, p1 = (u32)(r.x >> 32), p2 = (u32)r.y, p3 = (u32)(r.y >> 32) & 3u;
-                const u32 sh = 2u * (e >> 9);      // (<= 2 (w - 1) = 34)
-                const bool up = sh >= 32u;
-                const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2;
-                const u32 kl = __builtin_amdgcn_alignbit(a1, a0, sh), kh = __builtin_amdgcn_alignbit(a2, a1, sh) & hmask;
-                return ((u64)kh << 32) | kl;
-            };
             const u32 odd = off & 1u;
             if (odd && tid == 0 && n_km) {
                 __builtin_nontemporal_store(key_of(0), &ok[0]);
@@ -2236,7 +2332,7 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
             }
         }
         if (tid == 0)
-            shared_flag[par ^ 1] = 0;              // (the other parity's flag: its bucket is done with it)
+            shared_flag[par ^ 1] = multi_flag[par ^ 1] = 0;   // (the other parity's flags: its bucket is done with them)
         par ^= 1;
         if (!has_next)
             break;
