@@ -1650,10 +1650,22 @@ __global__ __launch_bounds__(SKR_NT, 8) void sk_regroup_kernel(const Node *__res
             const u32 r = tid + j * SKR_NT;
             dig[j] = 0;
             rank[j] = 0;
-            if (r < n_tile) {
-                const u64 m = reinterpret_cast<const u64 *>(src + t0 + r)[1];
-                dig[j] = (u32)(m >> 59) & 15u;
-                rank[j] = atomicAdd(&tcnt[dig[j]], 1u);      // (16 hot addresses: the tile's share of this is small)
+            const bool in = r < n_tile;
+            if (in)
+                dig[j] = (u32)(reinterpret_cast<const u64 *>(src + t0 + r)[1] >> 59) & 15u;
+            // one atomic per wave and digit present: a long bucket is a repeat's, its records share the m-mer and with it
+            // d2 -- a lane's own atomic would be 8,192 additions to ONE address per tile
+            u64 todo = __ballot(in);
+            while (todo) {
+                const u32 d = (u32)__builtin_amdgcn_readlane((int)dig[j], (int)__builtin_ctzll(todo));
+                const u64 same = __ballot(in && dig[j] == d);
+                u32 base = 0;
+                if (lane == (int)__builtin_ctzll(same))
+                    base = atomicAdd(&tcnt[d], (u32)__popcll(same));
+                base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
+                if (in && dig[j] == d)
+                    rank[j] = base + (u32)__popcll(same & (((u64)1 << lane) - 1));
+                todo &= ~same;
             }
         }
         __syncthreads();
@@ -2085,6 +2097,11 @@ constexpr int SKQ_KMERS = 4096;                  // sk_count_cap(): most k-mers 
 constexpr int SKQ_VSLOTS = 1024;                 // record table (at most 512 entries)
 constexpr int SKQ_DIRTY_MAX = 640;               // most k-mers of sharing records that are counted in those slots
 
+#ifdef SKQ_STORE_PLAIN                            // (A/B builds only: tools/build_variant.sh WORK x.so -DSKQ_STORE_PLAIN)
+#define SKQ_STORE(v, p) (*(p) = (v))
+#else
+#define SKQ_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
                                                                    const u32 *__restrict__ list_off, u32 n_list,
                                                                    const ull2_t *__restrict__ recs, int k,
@@ -2246,8 +2263,8 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                     const u32 c = cpos[e & 511u];
                     const u64 key = key_of(i);
                     if (c != 0xFFFFu) {
-                        __builtin_nontemporal_store(key, &ok[c + (e >> 9)]);
-                        __builtin_nontemporal_store(1u, &oc[c + (e >> 9)]);
+                        SKQ_STORE(key, &ok[c + (e >> 9)]);
+                        SKQ_STORE(1u, &oc[c + (e >> 9)]);
                     } else if (key == ~(u64)0) {
                         atomicAdd(&d_ones, 1u);    // (the 32-base k-mer GG..G: the empty slot's value)
                     } else {
@@ -2306,8 +2323,8 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
             // tops out near 3.3 TB/s on this chip); the pairs start on an even output slot.
             const u32 odd = off & 1u;
             if (odd && tid == 0 && n_km) {
-                __builtin_nontemporal_store(key_of(0), &ok[0]);
-                __builtin_nontemporal_store(1u, &oc[0]);
+                SKQ_STORE(key_of(0), &ok[0]);
+                SKQ_STORE(1u, &oc[0]);
             }
             for (u32 i = odd + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
                 const u64 k0 = key_of(i);
@@ -2318,11 +2335,11 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                     ull2_t kk;
                     kk.x = k0;
                     kk.y = key_of(i + 1);
-                    __builtin_nontemporal_store(kk, reinterpret_cast<ull2_t *>(&ok[i]));
-                    __builtin_nontemporal_store((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
+                    SKQ_STORE(kk, reinterpret_cast<ull2_t *>(&ok[i]));
+                    SKQ_STORE((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
                 } else {
-                    __builtin_nontemporal_store(k0, &ok[i]);
-                    __builtin_nontemporal_store(1u, &oc[i]);
+                    SKQ_STORE(k0, &ok[i]);
+                    SKQ_STORE(1u, &oc[i]);
                 }
             }
             if (tid == 0) {

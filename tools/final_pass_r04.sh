@@ -18,6 +18,8 @@ if [ "$PART" = "bench" ] || [ "$PART" = "all" ]; then
   $B --config 2 --motif 1000 --no-cpu-baseline > $O/bench_cfg2_motif1000.json 2>> $O/bench.err || exit 1
   $B --config 3 > $O/bench_cfg3.json 2>> $O/bench.err || exit 1
   $B --config 3 --motif 1000 --no-cpu-baseline > $O/bench_cfg3_motif1000.json 2>> $O/bench.err || exit 1
+  $B --config 3 --genome-like --no-cpu-baseline > $O/bench_cfg3_genome_like.json 2>> $O/bench.err || exit 1
+  $B --config 2 --genome-like --no-cpu-baseline > $O/bench_cfg2_genome_like.json 2>> $O/bench.err || exit 1
   $B --config 5 --steps 200 --warmup 20 > $O/bench_cfg5.json 2>> $O/bench.err || exit 1
   $B --config 5 --steps 200 --warmup 20 --pattern ACGNNNNNNNNNNNNNNNNNN --no-cpu-baseline > $O/bench_cfg5_sel64.json 2>> $O/bench.err || exit 1
   $B --config 6 --no-cpu-baseline > $O/bench_cfg6.json 2>> $O/bench.err || exit 1
