@@ -2097,10 +2097,16 @@ constexpr int SKQ_KMERS = 4096;                  // sk_count_cap(): most k-mers 
 constexpr int SKQ_VSLOTS = 1024;                 // record table (at most 512 entries)
 constexpr int SKQ_DIRTY_MAX = 640;               // most k-mers of sharing records that are counted in those slots
 
-#ifdef SKQ_STORE_PLAIN                            // (A/B builds only: tools/build_variant.sh WORK x.so -DSKQ_STORE_PLAIN)
+// (A/B builds only: tools/build_variant.sh WORK x.so -DSKQ_STORE_PLAIN / -DSKQ_KEYS_PLAIN / -DSKQ_COUNTS_PLAIN)
+#if defined(SKQ_STORE_PLAIN) || defined(SKQ_KEYS_PLAIN)
 #define SKQ_STORE(v, p) (*(p) = (v))
 #else
 #define SKQ_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+#if defined(SKQ_STORE_PLAIN) || defined(SKQ_COUNTS_PLAIN)
+#define SKQ_STOREC(v, p) (*(p) = (v))
+#else
+#define SKQ_STOREC(v, p) __builtin_nontemporal_store(v, p)
 #endif
 __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *__restrict__ fin, const u32 *__restrict__ list,
                                                                    const u32 *__restrict__ list_off, u32 n_list,
@@ -2264,7 +2270,7 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                     const u64 key = key_of(i);
                     if (c != 0xFFFFu) {
                         SKQ_STORE(key, &ok[c + (e >> 9)]);
-                        SKQ_STORE(1u, &oc[c + (e >> 9)]);
+                        SKQ_STOREC(1u, &oc[c + (e >> 9)]);
                     } else if (key == ~(u64)0) {
                         atomicAdd(&d_ones, 1u);    // (the 32-base k-mer GG..G: the empty slot's value)
                     } else {
@@ -2320,13 +2326,18 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
         } else {
             // ---- every k-mer of the bucket is the only one of its kind: (key, 1) groups, k-mer i at slot off + i
             // Two k-mers per thread and round: 16 bytes of keys and 8 of counts per lane, nontemporal (a plain store stream
-            // tops out near 3.3 TB/s on this chip); the pairs start on an even output slot.
-            const u32 odd = off & 1u;
-            if (odd && tid == 0 && n_km) {
-                SKQ_STORE(key_of(0), &ok[0]);
-                SKQ_STORE(1u, &oc[0]);
+            // tops out near 3.3 TB/s on this chip).
+            // The pairs start on a 32-slot boundary of the arrays (256 bytes of keys, 128 of counts), so that a wave's stores
+            // cover whole lines; the k-mers before that boundary leave one per thread.  (Measured, 3 Gbase, 14 runs each on
+            // one box: pairs from the first even slot 8.07 - 8.34 ms with runs of 10.0 - 10.8 in between -- typically a box's
+            // first -- against 7.93 - 8.04 with one of 8.7, when every kernel was 5 - 8 % slower; plain stores throughout
+            // 8.45 - 9.3; plain stores for the partial lines at a bucket's ends: no gain.)
+            const u32 head = (32u - (off & 31u)) & 31u;
+            if ((u32)tid < head && (u32)tid < n_km) {
+                SKQ_STORE(key_of((u32)tid), &ok[tid]);
+                SKQ_STOREC(1u, &oc[tid]);
             }
-            for (u32 i = odd + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
+            for (u32 i = head + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
                 const u64 k0 = key_of(i);
                 if (SK_DBG(512)) {
                     if (k0 == 0x123456789ull)
@@ -2336,10 +2347,10 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                     kk.x = k0;
                     kk.y = key_of(i + 1);
                     SKQ_STORE(kk, reinterpret_cast<ull2_t *>(&ok[i]));
-                    SKQ_STORE((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
+                    SKQ_STOREC((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
                 } else {
                     SKQ_STORE(k0, &ok[i]);
-                    SKQ_STORE(1u, &oc[i]);
+                    SKQ_STOREC(1u, &oc[i]);
                 }
             }
             if (tid == 0) {

@@ -3,7 +3,7 @@
 TAG=$1; shift
 mkdir -p gpurun_out/$TAG
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for L in "$@"; do
     N=$(basename $L .so)
     DNAGPU_LIB_PATH=$GRAFT_REPO_ROOT/$L timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$TAG/${N}_$rep.json 2> gpurun_out/$TAG/${N}_$rep.err
