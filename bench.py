@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--k", type=int, default=None, help="override the config's k")
     ap.add_argument("--motif", type=int, default=0,
                     help="repeat-rich variant (SURVEY.md 8(d)): tile the first MOTIF bases over the second half")
+    ap.add_argument("--table-host-starts", action="store_true",
+                    help="config 6: hand the sequence starts over as a host array with every count (dnagpu_count_kmers_batch: "
+                         "8 bytes per sequence cross the bus inside the timed step) instead of making them resident once")
     ap.add_argument("--genome-like", action="store_true",
                     help="count configs, single GPU: instead of uniform random bases a genome-LIKE sequence generated on the host "
                          "(tools/genome_like.py: an Alu-like family, exact segmental duplications, microsatellites) and uploaded")
@@ -197,10 +200,14 @@ def main():
         dna = ctx.synth(seed, n_bases, motif_len=args.motif)
         starts = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
         n_kmers = n_reads * max(read_len - k + 1, 0)                 # the rows of the table: every read's own
-        extra["table"] = {"reads": n_reads, "read_len": read_len}
+        extra["table"] = {"reads": n_reads, "read_len": read_len,
+                          "boundaries": "host array per call (dnagpu_count_kmers_batch)" if args.table_host_starts else
+                                        "resident (dnagpu_dna_set_sequences once, dnagpu_count_kmers_table per step)"}
+        if not args.table_host_starts:
+            dna.set_sequences(starts)              # inputs resident in HBM when the timed region starts
 
         def count_fn(dna_, k_):
-            return ctx.count_kmers_batch(dna_, starts, k_)
+            return ctx.count_kmers_batch(dna_, starts, k_) if args.table_host_starts else ctx.count_kmers_table(dna_, k_)
 
         def step():
             h = count_fn(dna, k)
@@ -367,7 +374,7 @@ def main():
                 f"k-mers/sec for k={k} count over {n_bases} synthetic bases; % of HBM-read roofline"
             eng = "" if world > 1 else (", ordered groups (MSD radix tree)" if sorted_result[0] else ", unordered groups (super-k-mer partitioning)")
             tbl = (f" as a table of {extra['table']['reads']} sequences of {extra['table']['read_len']} bases "
-                   "(dnagpu_count_kmers_batch: no k-mer spans two sequences)") if "table" in extra else ""
+                   "(dnagpu_count_kmers_table: no k-mer spans two sequences)") if "table" in extra else ""
             workload = (f"config {args.config}: k={k} count over {n_bases} synthetic bases{tbl} (splitmix64 seed {seed:#x}"
                         f"{', motif ' + str(args.motif) if args.motif else ''}){eng}, "
                         f"{'single GPU' if world == 1 else f'sharded over {world} GPUs, ' + extra.get('exchange', '')}")

@@ -120,6 +120,10 @@ def lib():
     L.dnagpu_count_kmers_unordered.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_hist_is_sorted.argtypes = [vp]
     L.dnagpu_count_kmers_batch.argtypes = [vp, vp, u64p, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.dnagpu_dna_set_sequences.argtypes = [vp, vp, u64p, C.c_uint64]
+    L.dnagpu_dna_sequences.argtypes = [vp]
+    L.dnagpu_dna_sequences.restype = C.c_uint64
+    L.dnagpu_count_kmers_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.dnagpu_sk_buckets.argtypes = [vp, C.c_uint64, C.c_int]
     L.dnagpu_sk_records.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.dnagpu_records_buckets.argtypes = [vp]
@@ -264,6 +268,16 @@ class Dna:
         out = np.empty(max(nw, 1), dtype=np.uint64)
         _chk(lib().dnagpu_dna_download(self.ctx.h, self.h, out.ctypes.data_as(u64p)))
         return out[:nw]
+
+    def set_sequences(self, seq_starts):
+        """this packed stream is a TABLE of sequences: seq_starts = the first base of each + the total (n_seqs + 1 entries),
+        kept on the device beside it (dnagpu_dna_set_sequences) for Context.count_kmers_table"""
+        st = np.ascontiguousarray(seq_starts, dtype=np.uint64)
+        _chk(lib().dnagpu_dna_set_sequences(self.ctx.h, self.h, st.ctypes.data_as(u64p), max(len(st) - 1, 0)))
+
+    @property
+    def n_sequences(self):
+        return int(lib().dnagpu_dna_sequences(self.h))
 
     def free(self):
         if self.h:
@@ -530,6 +544,12 @@ class Context:
         st = np.ascontiguousarray(seq_starts, dtype=np.uint64)
         h = C.c_void_p()
         _chk(lib().dnagpu_count_kmers_batch(self.h, dna.h, st.ctypes.data_as(u64p), max(len(st) - 1, 0), k, C.byref(h)))
+        return Hist(self, h)
+
+    def count_kmers_table(self, dna, k):
+        """the same over a table made resident with Dna.set_sequences: nothing crosses the bus per count"""
+        h = C.c_void_p()
+        _chk(lib().dnagpu_count_kmers_table(self.h, dna.h, k, C.byref(h)))
         return Hist(self, h)
 
     # ---- the unordered count in two halves (rows on several GPUs: sharded.count_sharded_exchange_records)

@@ -218,6 +218,10 @@ struct dnagpu_dna {
     u64 n_words;
     u64 n_bases;
     bool owned;
+    // a TABLE of sequences (dnagpu_dna_set_sequences): where every sequence starts, resident beside the packed stream
+    u64 *seq_starts = nullptr;    // n_seqs + 1 offsets (pool memory)
+    u32 *seq_marks = nullptr;     // one bit per base, set where a sequence starts (pool memory)
+    u64 n_seqs = 0, n_mark_words = 0;
 };
 
 struct dnagpu_hist {
@@ -874,6 +878,10 @@ extern "C" void dnagpu_dna_free(dnagpu_ctx *ctx, dnagpu_dna *dna)
         return;
     if (dna->owned && ctx)
         pool_free(ctx, dna->words);
+    if (ctx && dna->seq_starts)
+        pool_free(ctx, dna->seq_starts);
+    if (ctx && dna->seq_marks)
+        pool_free(ctx, dna->seq_marks);
     delete dna;
 }
 
@@ -2433,16 +2441,10 @@ extern "C" int dnagpu_count_kmers_unordered(dnagpu_ctx *ctx, const dnagpu_dna *d
 }
 
 // ---- GROUP BY kmer, count(*) FROM a table of sequences, LATERAL generate_kmers(sequence, k) (test.sql:140-150)
-extern "C" int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs,
-                                        int k, dnagpu_hist **out)
+// the rows of a table: every sequence's own generate_kmers rows (none for a sequence shorter than k); BAD_ARG unless the
+// starts are ascending from 0 to the stream's length
+static int table_rows_host(const dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs, int k, u64 *rows_out)
 {
-    return guarded([&]() -> int {
-    if (!ctx || !dna || !out || (n_seqs && !seq_starts))
-        return DNAGPU_ERR_BAD_ARG;
-    if (k < 1 || k > 32)
-        return DNAGPU_ERR_INVALID_K;               // dna.c:771-773, raised by the first row's generate_kmers call
-    *out = nullptr;
-    // the rows of the table: every sequence's own generate_kmers rows (none for a sequence shorter than k)
     u64 rows = 0;
     for (u64 i = 0; i < n_seqs; i++) {
         if (seq_starts[i + 1] < seq_starts[i])
@@ -2455,24 +2457,15 @@ extern "C" int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, 
         return DNAGPU_ERR_BAD_ARG;
     if (n_seqs == 0 && dna->n_bases != 0)
         return DNAGPU_ERR_BAD_ARG;
-    if (rows > 0xFFFFFFFFull || dna->n_bases > 0xFFFFFFFFull)
-        return DNAGPU_ERR_TOO_LARGE;
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (rows == 0)
-        return count_core(ctx, nullptr, 0, 0, k, nullptr, out);
-    if (n_seqs == 1)                               // one sequence: the plain count
-        return count_core(ctx, dna, 0, rows, k, nullptr, out, 0, 0, 0, 1, true);
+    *rows_out = rows;
+    return DNAGPU_OK;
+}
+
+// the count over a table whose marks are in device memory (the caller's PoolScope or the dna's own)
+static int count_table(dnagpu_ctx *ctx, const dnagpu_dna *dna, const u32 *marks, u64 n_mark_words, u64 rows, int k, dnagpu_hist **out)
+{
     PoolScope ps(ctx);
     hipStream_t st = ctx->stream;
-    // ---- the marks: one bit per base, set where a sequence starts
-    const u64 n_mark_words = dna->n_bases / 32 + 3;
-    u32 *marks = nullptr;
-    u64 *d_starts = nullptr;
-    RC_TRY(ps.alloc((size_t)n_mark_words, &marks));
-    RC_TRY(ps.alloc((size_t)n_seqs + 1, &d_starts));
-    HIP_TRY(hipMemcpyAsync(d_starts, seq_starts, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(launch_batch_marks(d_starts, n_seqs, marks, n_mark_words, st));
-    HIP_TRY(hipStreamSynchronize(st));             // (seq_starts is the caller's: not kept behind the call)
     const u64 n_windows = dna->n_bases - (u64)k + 1;   // (rows > 0: some sequence has k bases)
     // ---- long k-mers of long tables: the super-k-mer engine, its level 0 blind to the rows across sequence starts
     const bool force_sk = (ctx->debug_flags & DNAGPU_DEBUG_FORCE_SUPERKMER) && k >= sk_min_k() && rows >= 64;
@@ -2509,6 +2502,118 @@ extern "C" int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, 
         return DNAGPU_ERR_INTERNAL;
     }
     return count_core(ctx, nullptr, 0, rows, k, keys, out);
+}
+
+extern "C" int dnagpu_count_kmers_batch(dnagpu_ctx *ctx, const dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs,
+                                        int k, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || !out || (n_seqs && !seq_starts))
+        return DNAGPU_ERR_BAD_ARG;
+    if (k < 1 || k > 32)
+        return DNAGPU_ERR_INVALID_K;               // dna.c:771-773, raised by the first row's generate_kmers call
+    *out = nullptr;
+    u64 rows = 0;
+    RC_TRY(table_rows_host(dna, seq_starts, n_seqs, k, &rows));
+    if (rows > 0xFFFFFFFFull || dna->n_bases > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (rows == 0)
+        return count_core(ctx, nullptr, 0, 0, k, nullptr, out);
+    if (n_seqs == 1)                               // one sequence: the plain count
+        return count_core(ctx, dna, 0, rows, k, nullptr, out, 0, 0, 0, 1, true);
+    PoolScope ps(ctx);
+    hipStream_t st = ctx->stream;
+    // ---- the marks: one bit per base, set where a sequence starts
+    const u64 n_mark_words = dna->n_bases / 32 + 3;
+    u32 *marks = nullptr;
+    u64 *d_starts = nullptr;
+    RC_TRY(ps.alloc((size_t)n_mark_words, &marks));
+    RC_TRY(ps.alloc((size_t)n_seqs + 1, &d_starts));
+    HIP_TRY(hipMemcpyAsync(d_starts, seq_starts, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_batch_marks(d_starts, n_seqs, marks, n_mark_words, st));
+    HIP_TRY(hipStreamSynchronize(st));             // (seq_starts is the caller's: not kept behind the call)
+    return count_table(ctx, dna, marks, n_mark_words, rows, k, out);
+    });
+}
+
+// The table's boundaries made resident: validated, uploaded, and the marks built ONCE; dnagpu_count_kmers_table then counts
+// it for any k with nothing crossing the bus (at 10^7 reads the starts are 80 MB: 5.8 ms of a 14.4 ms call).
+extern "C" int dnagpu_dna_set_sequences(dnagpu_ctx *ctx, dnagpu_dna *dna, const uint64_t *seq_starts, uint64_t n_seqs)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || (n_seqs && !seq_starts))
+        return DNAGPU_ERR_BAD_ARG;
+    u64 rows1 = 0;
+    RC_TRY(table_rows_host(dna, seq_starts, n_seqs, 1, &rows1));
+    if (dna->n_bases > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dna->seq_starts)
+        pool_free(ctx, dna->seq_starts);
+    if (dna->seq_marks)
+        pool_free(ctx, dna->seq_marks);
+    dna->seq_starts = nullptr;
+    dna->seq_marks = nullptr;
+    dna->n_seqs = dna->n_mark_words = 0;
+    if (n_seqs == 0)
+        return DNAGPU_OK;                          // (an empty table over an empty stream: nothing to keep)
+    hipStream_t st = ctx->stream;
+    const u64 n_mark_words = dna->n_bases / 32 + 3;
+    void *ds = nullptr, *dm = nullptr;
+    RC_TRY(pool_alloc(ctx, (size_t)(n_seqs + 1) * 8, &ds));
+    int rc = pool_alloc(ctx, (size_t)n_mark_words * 4, &dm);
+    if (rc != DNAGPU_OK) {
+        pool_free(ctx, ds);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(ds, seq_starts, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_batch_marks(static_cast<const u64 *>(ds), n_seqs, static_cast<u32 *>(dm), n_mark_words, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);              // (seq_starts is the caller's: not kept behind the call)
+    if (e != hipSuccess) {
+        pool_free(ctx, ds);
+        pool_free(ctx, dm);
+        set_err("set_sequences: %s", hipGetErrorString(e));
+        return DNAGPU_ERR_HIP;
+    }
+    dna->seq_starts = static_cast<u64 *>(ds);
+    dna->seq_marks = static_cast<u32 *>(dm);
+    dna->n_seqs = n_seqs;
+    dna->n_mark_words = n_mark_words;
+    return DNAGPU_OK;
+    });
+}
+
+extern "C" uint64_t dnagpu_dna_sequences(const dnagpu_dna *dna) { return dna ? dna->n_seqs : 0; }
+
+extern "C" int dnagpu_count_kmers_table(dnagpu_ctx *ctx, const dnagpu_dna *dna, int k, dnagpu_hist **out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !dna || !out)
+        return DNAGPU_ERR_BAD_ARG;
+    if (k < 1 || k > 32)
+        return DNAGPU_ERR_INVALID_K;
+    *out = nullptr;
+    if (dna->n_seqs == 0 && dna->n_bases != 0)
+        return DNAGPU_ERR_BAD_ARG;                 // (no dnagpu_dna_set_sequences before)
+    HIP_TRY(hipSetDevice(ctx->device));
+    u64 rows = 0;
+    if (dna->n_seqs) {
+        PoolScope ps(ctx);
+        u64 *d_rows = nullptr;
+        RC_TRY(ps.alloc(1, &d_rows));
+        HIP_TRY(launch_batch_rows(dna->seq_starts, dna->n_seqs, k, d_rows, ctx->stream));
+        RC_TRY(read_back(ctx, &rows, d_rows, 8));
+    }
+    if (rows > 0xFFFFFFFFull)
+        return DNAGPU_ERR_TOO_LARGE;
+    if (rows == 0)
+        return count_core(ctx, nullptr, 0, 0, k, nullptr, out);
+    if (dna->n_seqs == 1)
+        return count_core(ctx, dna, 0, rows, k, nullptr, out, 0, 0, 0, 1, true);
+    return count_table(ctx, dna, dna->seq_marks, dna->n_mark_words, rows, k, out);
     });
 }
 

@@ -131,6 +131,33 @@ hipError_t launch_batch_marks(const u64 *starts, u64 n_seqs, u32 *marks, u64 n_m
     return hipGetLastError();
 }
 
+// rows of the table for one k: the sum over the sequences of max(0, length - k + 1) (a resident table is counted for any
+// k without its starts travelling again)
+__global__ __launch_bounds__(256) void batch_rows_kernel(const u64 *__restrict__ starts, u64 n_seqs, u32 k,
+                                                         unsigned long long *__restrict__ rows)
+{
+    u64 sum = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_seqs; i += (u64)gridDim.x * blockDim.x) {
+        const u64 len = starts[i + 1] - starts[i];
+        sum += len >= k ? len - k + 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum)
+        atomicAdd(rows, (unsigned long long)sum);
+}
+
+hipError_t launch_batch_rows(const u64 *starts, u64 n_seqs, int k, u64 *rows, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(rows, 0, sizeof(u64), s);
+    if (e != hipSuccess || n_seqs == 0)
+        return e;
+    const u64 blocks = (n_seqs + 1023) / 1024;
+    hipLaunchKernelGGL(batch_rows_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, starts, n_seqs, (u32)k,
+                       reinterpret_cast<unsigned long long *>(rows));
+    return hipGetLastError();
+}
+
 // The keys of the table's rows for the engines that take keys (short k-mers, short tables): a wave owns 1024 consecutive
 // rows, 16 rounds of one row per lane; a row is kept when no sequence starts among the k - 1 bases behind its first (its
 // window lies in one sequence).  The wave's kept keys wait in registers, one returning add reserves their slots, and every

@@ -170,6 +170,8 @@ hipError_t launch_merge_compact(const u64 *tkeys, const u32 *tcnt, u64 t_slots, 
 // ---- a table of sequences in one packed stream (extract_kernels.hip)
 // marks: bit b set where a sequence starts at base b (starts[1 .. n_seqs - 1]; the buffer is zeroed here)
 hipError_t launch_batch_marks(const u64 *starts, u64 n_seqs, u32 *marks, u64 n_mark_words, hipStream_t s);
+// *rows = sum over the sequences of max(0, length - k + 1)
+hipError_t launch_batch_rows(const u64 *starts, u64 n_seqs, int k, u64 *rows, hipStream_t s);
 // the keys of the rows of the table -- windows [p, p + k) of rows [0, n_rows) that reach across no mark -- in no
 // particular order; *cursor (zeroed here) ends as their number
 hipError_t launch_batch_keys(const u64 *words, u64 n_words, const u32 *marks, u64 n_mark_words, u64 n_rows, int k, u64 *out_keys,

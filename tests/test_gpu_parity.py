@@ -1184,8 +1184,9 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
     words, starts = table_of_sequences(0xBA7C4 + n_seqs, n_seqs, lo, hi)
     n = int(starts[-1])
     d = ctx.upload(words, n)
+    want = {}
     for k in (31, 21, 32, 25, 20, 10, 3):
-        ok, oc = orc.count_keys(orc.generate_kmers_table(words, starts, k))
+        ok, oc = want[k] = orc.count_keys(orc.generate_kmers_table(words, starts, k))
         for forced in (True, False):
             if forced and k < 20:
                 continue
@@ -1200,6 +1201,23 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
                 check_hist(h, ok, oc, what)
             else:
                 check_hist_unordered(h, ok, oc, what)
+            h.free()
+    # the same table made resident (dnagpu_dna_set_sequences) and counted for several k (dnagpu_count_kmers_table)
+    d.set_sequences(starts)
+    assert d.n_sequences == n_seqs
+    for k in (31, 20, 10):
+        ok, oc = want[k]
+        for forced in (True, False):
+            if forced and k < 20:
+                continue
+            ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER if forced else 0)
+            try:
+                h = ctx.count_kmers_table(d, k)
+            finally:
+                ctx.set_debug(0)
+            what = f"resident table of {n_seqs} sequences, k={k}, {'records' if forced else 'default engine'}"
+            assert h.total == int(oc.sum()), what
+            check_hist(h, ok, oc, what) if h.is_sorted else check_hist_unordered(h, ok, oc, what)
             h.free()
     d.free()
 
@@ -1260,7 +1278,22 @@ def test_count_kmers_batch_is_the_plain_count_for_one_sequence_and_checks_its_ar
     with pytest.raises(pkg.DnaGpuError) as ei:
         ctx.count_kmers_batch(d, [0, n], 33)
     assert ei.value.code == 1 and "between 1 and 32" in str(ei.value)      # dna.c:773
-    h = ctx.count_kmers_batch(d, [0, 10, 20, n], 31) if False else ctx.count_kmers_batch(d, [0, 10, 20, 30, n - 5, n], 32)
+    with pytest.raises(pkg.DnaGpuError) as ei:     # no sequences set on this stream
+        ctx.count_kmers_table(d, 31)
+    assert ei.value.code == 5
+    for bad in ([0, n - 1], [0, 200, 100, n]):
+        with pytest.raises(pkg.DnaGpuError) as ei:
+            d.set_sequences(bad)
+        assert ei.value.code == 5 and d.n_sequences == 0
+    d.set_sequences([0, 100, n])
+    d.set_sequences([0, n])                        # (replaces the first set: one sequence, the plain count)
+    h = ctx.count_kmers_table(d, 31)
+    check_hist(h, ok, oc, "one sequence, resident") if h.is_sorted else check_hist_unordered(h, ok, oc, "one sequence, resident")
+    h.free()
+    with pytest.raises(pkg.DnaGpuError) as ei:
+        ctx.count_kmers_table(d, 0)
+    assert ei.value.code == 1
+    h = ctx.count_kmers_batch(d, [0, 10, 20, 30, n - 5, n], 32)
     keys = orc.generate_kmers_table(words, np.array([0, 10, 20, 30, n - 5, n], dtype=np.uint64), 32)
     ok, oc = orc.count_keys(keys)
     check_hist(h, ok, oc, "short sequences around a long one") if h.is_sorted else check_hist_unordered(h, ok, oc, "short sequences around a long one")
