@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
     __shared__ u32 big_list[64];
     __shared__ u32 uniform_bits[BINS / 32];   // bit b: bin b is long and a wave has placed its heavy members (P)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
     u32 lq = blockIdx.x;                       // MIXED: position in `list`
     u32 li = blockIdx.x;
     if (MIXED)
@@ -1519,6 +1519,8 @@ __global__ __launch_bounds__(NT, MINW) void leaves_kernel(const Node *__restrict
         }
         const bool has_next = ln < n_leaves;
         const Node nn = leaves[has_next ? ln : li];           // wave-uniform: a scalar load, used later
+        asm volatile("" : "+v"(tid));              // (nothing derived from the thread index is held across leaves)
+        const int lane = tid & 63, wave = tid >> 6;
         __syncthreads();                           // A/H of the previous leaf are dead
         // Every path through an iteration "uses" the prefetched keys here.  Without this a leaf that
         // never reads them (a single-key leaf) leaves loads in flight, and the compiler guards the

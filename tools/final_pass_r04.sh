@@ -46,6 +46,8 @@ if [ "$PART" = "prof" ] || [ "$PART" = "all" ]; then
   cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_summary_3e9.txt
   python3 tools/pmc_traffic.py gpurun_out/pmc_$TAG/summary.txt profiles/${TAG}_pmc_summary_3e9.txt > $O/traffic.json
   echo "pmc done"
+  bash tools/run_pmc_sq.sh ${TAG}_sq 1e9 31 > $O/pmc_sq_1e9.txt 2>&1
+  echo "sq counters done"
   timeout -k 10 300 python3 tools/records_probe.py 3e9 31 8 350 > $O/records_probe.log 2>&1
   timeout -k 10 120 python3 tools/overhead_probe.py > $O/overhead_probe.log 2>&1
   echo "probes done"
