@@ -259,6 +259,13 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
     const size_t asked = bytes;
     const bool guard = (ctx->debug_flags & DNAGPU_DEBUG_GUARD_POOL) != 0;
     bytes = (bytes + (guard ? POOL_GUARD : 0) + 255) & ~(size_t)255;
+    // size classes (eight per power of two above 64 KB: at most 12.5 % more than asked): a work buffer whose size moves a
+    // little from call to call (key ranges of the oversize buckets, sampled regions) finds the block of the call before
+    // instead of a hipMalloc -- which costs milliseconds to a second for buffers of gigabytes
+    if (bytes > ((size_t)1 << 16)) {
+        const size_t g = (size_t)1 << (60 - __builtin_clzll((unsigned long long)bytes));
+        bytes = (bytes + g - 1) & ~(g - 1);
+    }
     const size_t want = bytes;
     auto finish = [&](PoolBlock &b) -> int {
         b.in_use = true;
@@ -282,6 +289,9 @@ static int pool_alloc(dnagpu_ctx *ctx, size_t bytes, void **out)
         return finish(ctx->pool[best]);
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
+#ifdef DNAGPU_STAMPS
+    fprintf(stderr, "[pool] hipMalloc %zu bytes (%zu blocks pooled)\n", want, ctx->pool.size());
+#endif
     if (e != hipSuccess) {
         // give pooled-but-idle memory back and retry once
         (void)hipGetLastError();
@@ -1379,7 +1389,12 @@ constexpr u64 SK_LEAF_MEAN = 2500;               // planned k-mers per final buc
 // expansion; below that it is regrouped like the others, and its long final buckets (thousands to millions of copies of a
 // few k-mers) are what sk_count_big is for.  Final buckets beyond SK_BIG_LIMIT k-mers are expanded without trying.
 constexpr u64 SK_MID_LIMIT = (u64)1 << 27;
-constexpr u32 SK_MID_RECORDS = 1u << 19;           // (a mid bucket is regrouped by one workgroup: 64 tiles, twice)
+// (a mid bucket is regrouped by ONE workgroup, tile after tile, twice: beyond eight tiles the chunked split below, many
+// workgroups per bucket, is faster -- 249 Mbase of a tiled 1000-base motif: sk_regroup 0.64 ms at 2^19, sk_heavy_split 0.31 at 2^16)
+#ifndef SK_MID_RECORDS_LOG2
+#define SK_MID_RECORDS_LOG2 16
+#endif
+constexpr u32 SK_MID_RECORDS = 1u << SK_MID_RECORDS_LOG2;
 constexpr u64 SK_BIG_LIMIT = 0xFFFFFFFFull;
 // Level 1 splits a coarse bucket 512 ways, not 1024: a tile of 8192 records then leaves in runs of 16 records (256
 // bytes) instead of 8 -- sk_scatter1 3.6 - 3.9 instead of 4.9 - 5.2 ms at 3 Gbase (A/B on one box) -- and level 0 takes

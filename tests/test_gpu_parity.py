@@ -944,6 +944,59 @@ def test_count_kmers_owned(ctx, n_owners):
         d.free()
 
 
+def pack_codes(codes):
+    """2-bit codes (A=0 T=1 C=2 G=3) -> packed words in the reference's layout (dna.c:114-128)"""
+    n = len(codes)
+    pad = np.zeros((n + 31) // 32 * 32, dtype=np.uint64)
+    pad[:n] = codes
+    sh = np.arange(32, dtype=np.uint64) * np.uint64(2)
+    return (pad.reshape(-1, 32) << sh).sum(axis=1, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("kind", ["scattered", "all-G", "many"])
+@pytest.mark.parametrize("k", [32, 31, 21])
+def test_count_unordered_copies_are_counted_in_place(ctx, pkg, kind, k):
+    """sk_count_clean's buckets in which SOME records share k-mers: the sharing records' k-mers are counted in the record
+    table's slots, the others leave as (key, 1).  scattered: 150-base pieces copied to random places (a few sharing records
+    in nearly every bucket); all-G: copies of a piece around a run of 40 G -- at k = 32 the k-mer GG..G, the value of an
+    empty slot, is counted beside the table; many: one piece copied 3000 times (more sharing k-mers than the slots take:
+    those buckets go to sk_count)."""
+    n = 5_000_000
+    rng = np.random.default_rng(0xC0B1E5 + k)
+    c = rng.integers(0, 4, n, dtype=np.uint8)
+    if kind == "scattered":
+        for _ in range(n // 7500):
+            a, b = rng.integers(0, n - 150, 2)
+            c[b:b + 150] = c[a:a + 150].copy()
+    elif kind == "all-G":
+        piece = rng.integers(0, 4, 140, dtype=np.uint8)
+        piece[50:90] = 3
+        for b in rng.integers(0, n - 140, 40):
+            c[b:b + 140] = piece
+    else:
+        piece = rng.integers(0, 4, 100, dtype=np.uint8)
+        for b in rng.integers(0, n - 100, 3000):
+            c[b:b + 100] = piece
+    words = pack_codes(c)
+    d = ctx.upload(words, n)
+    ok, oc = orc.count_kmers(words, n, k)
+    if kind == "all-G" and k == 32:
+        assert ok[-1] == np.uint64(0xFFFFFFFFFFFFFFFF) and oc[-1] >= 40
+    ctx.set_debug(pkg.DEBUG_FORCE_SUPERKMER)
+    try:
+        ctx.set_profiling(True)
+        h = ctx.count_kmers_unordered(d, k)
+        names = [nm for nm, _ in ctx.last_phase_times()]
+        ctx.set_profiling(False)
+        assert "sk_count" in names, names
+        check_hist_unordered(h, ok, oc, f"copies {kind} k={k}")
+        h.free()
+    finally:
+        ctx.set_debug(0)
+        ctx.set_profiling(False)
+    d.free()
+
+
 @pytest.mark.parametrize("k", [32, 26, 20])
 def test_count_unordered_near_copies_every_key_width(ctx, pkg, k):
     """the expansion's keys travel mixed (key_mix is a bijection of the 2k-bit keys: 64 bits at k = 32, where the mixed
