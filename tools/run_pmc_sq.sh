@@ -2,4 +2,4 @@
 # tools/run_pmc_sq.sh <tag> [n_bases] [k]: the two SQ counter groups over one unordered count (instructions per kernel)
 TAG=${1:-sq}; N=${2:-1e9}; K=${3:-31}
 bash $GRAFT_REPO_ROOT/tools/pmc_sq.sh $TAG dna-sequences-pg-extension_amd/libdnagpu.so sk_once.py $N $K 2
-grep -E "sk_count_kernel|sk_scatter0|sk_scatter1|sk_regroup|kernel" $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/summary.txt | head -40
+cat $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/summary.txt
