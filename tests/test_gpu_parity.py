@@ -1238,8 +1238,8 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
     n = int(starts[-1])
     d = ctx.upload(words, n)
     want = {}
-    # (the long tables with three k only: the oracle's hash aggregate of 1.5 x 10^8 rows takes most of a minute per k)
-    for k in ((31, 21, 32, 25, 20, 10, 3) if n_seqs < 200_000 else (31, 20, 10)):
+    # (the long tables with two k only: the oracle's hash aggregate of 1.5 x 10^8 rows takes most of a minute per k)
+    for k in ((31, 21, 32, 25, 20, 10, 3) if n_seqs < 200_000 else (31, 10)):
         ok, oc = want[k] = orc.count_keys(orc.generate_kmers_table(words, starts, k))
         for forced in (True, False):
             if forced and k < 20:
@@ -1260,6 +1260,8 @@ def test_count_kmers_batch_table_of_sequences(ctx, pkg, n_seqs, lo, hi):
     d.set_sequences(starts)
     assert d.n_sequences == n_seqs
     for k in (31, 20, 10):
+        if k not in want:
+            continue
         ok, oc = want[k]
         for forced in (True, False):
             if forced and k < 20:
