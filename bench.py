@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--k", type=int, default=None, help="override the config's k")
     ap.add_argument("--motif", type=int, default=0,
                     help="repeat-rich variant (SURVEY.md 8(d)): tile the first MOTIF bases over the second half")
+    ap.add_argument("--keys-only", action="store_true",
+                    help="config 5: write the matching kmers only (what the SQL statement returns), not their positions too")
     ap.add_argument("--table-host-starts", action="store_true",
                     help="config 6: hand the sequence starts over as a host array with every count (dnagpu_count_kmers_batch: "
                          "8 bytes per sequence cross the bus inside the timed step) instead of making them resident once")
@@ -186,7 +188,8 @@ def main():
         dna = ctx.synth(seed, n_bases, motif_len=args.motif)
         flt = pkg.Filter.contains(cfg["pattern"])
         # outputs (keys and positions) stay in device memory, sized for every row
-        kb, pb = ctx.buffer_alloc(n_kmers * 8), ctx.buffer_alloc(n_kmers * 8)
+        kb = ctx.buffer_alloc(n_kmers * 8)
+        pb = None if args.keys_only else ctx.buffer_alloc(n_kmers * 8)
 
         def step():
             matches[0] = ctx.count_matches_device(dna, k, flt, 0, n_kmers, C.c_void_p(kb), C.c_void_p(pb), n_kmers)
@@ -338,7 +341,7 @@ def main():
         if is_filter:
             # dominant kernel: the write sweep (tests every row again, cuts and stores the matching keys + positions)
             dom = "filter_write"
-            out_bytes = 16 * matches[0]
+            out_bytes = (8 if args.keys_only else 16) * matches[0]
             if dom in means and means[dom] > 0:
                 alg_bytes = b_in + out_bytes
                 achieved = alg_bytes / (means[dom] * 1e-3) / 1e9
@@ -349,12 +352,14 @@ def main():
             job = {"read_fraction": round(b_in / t_step / 1e9 / HBM_PEAK_GBS, 5),
                    "alg_fraction": round((b_in + out_bytes) / t_step / 1e9 / HBM_PEAK_GBS, 4),
                    "alg_bytes_per_row": round((b_in + out_bytes) / n_kmers, 3),
-                   "note": "compulsory output counted as 16 B per match (key + position, both written)"}
+                   "note": ("output = the matching kmers, 8 B per match (what the SQL statement returns: rows of kmer)"
+                            if args.keys_only else
+                            "compulsory output counted as 16 B per match (key + position, both written)")}
             metric = (f"rows/sec scanned, qkmer @> fused into the k={k} extraction over {n_bases} synthetic bases; "
                       "% of HBM-read roofline")
             workload = (f"config 5: generate_kmers(dna,{k}) WHERE '{cfg['pattern']}' @> kmer over {n_bases} synthetic bases "
-                        f"(splitmix64 seed {seed:#x}{', motif ' + str(args.motif) if args.motif else ''}), keys + positions "
-                        "to device memory, single GPU")
+                        f"(splitmix64 seed {seed:#x}{', motif ' + str(args.motif) if args.motif else ''}), "
+                        f"{'keys' if args.keys_only else 'keys + positions'} to device memory, single GPU")
             unit = "rows/s"
         else:
             kern = {n_: m for n_, m in means.items() if phase_kind(n_)}

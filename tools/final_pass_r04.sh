@@ -22,6 +22,7 @@ if [ "$PART" = "bench" ] || [ "$PART" = "all" ]; then
   $B --config 2 --genome-like --no-cpu-baseline > $O/bench_cfg2_genome_like.json 2>> $O/bench.err || exit 1
   $B --config 5 --steps 200 --warmup 20 > $O/bench_cfg5.json 2>> $O/bench.err || exit 1
   $B --config 5 --steps 200 --warmup 20 --pattern ACGNNNNNNNNNNNNNNNNNN --no-cpu-baseline > $O/bench_cfg5_sel64.json 2>> $O/bench.err || exit 1
+  $B --config 5 --steps 200 --warmup 20 --keys-only --no-cpu-baseline > $O/bench_cfg5_keys_only.json 2>> $O/bench.err || exit 1
   $B --config 6 --no-cpu-baseline > $O/bench_cfg6.json 2>> $O/bench.err || exit 1
   $B --config 6 --table-host-starts --no-cpu-baseline > $O/bench_cfg6_host_starts.json 2>> $O/bench.err || exit 1
   $B --config 6 --k 21 --no-cpu-baseline > $O/bench_cfg6_k21.json 2>> $O/bench.err || exit 1
