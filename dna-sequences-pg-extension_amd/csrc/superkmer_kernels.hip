@@ -2228,15 +2228,17 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
             vtab[vslot] = ~(u64)0;                 // (the table is clean again for the next bucket)
         u64 *ok = out_keys + off;
         u32 *oc = out_counts + off;
-        auto key_of = [&](u32 i) -> u64 {
-            const u32 e = own[i];
-            const ull2_t r = lrec[e & 511u];
+        auto key_cut = [&](const ull2_t r, u32 e) -> u64 {
             const u32 p0 = (u32)r.x, p1 = (u32)(r.x >> 32), p2 = (u32)r.y, p3 = (u32)(r.y >> 32) & 3u;
             const u32 sh = 2u * (e >> 9);          // (<= 2 (w - 1) = 34)
             const bool up = sh >= 32u;
             const u32 a0 = up ? p1 : p0, a1 = up ? p2 : p1, a2 = up ? p3 : p2;
             const u32 kl = __builtin_amdgcn_alignbit(a1, a0, sh), kh = __builtin_amdgcn_alignbit(a2, a1, sh) & hmask;
             return ((u64)kh << 32) | kl;
+        };
+        auto key_of = [&](u32 i) -> u64 {
+            const u32 e = own[i];
+            return key_cut(lrec[e & 511u], e);
         };
         const u32 flag = shared_flag[par] | (multi_flag[par] << 1);
         if (flag) {
@@ -2338,14 +2340,20 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                 SKQ_STOREC(1u, &oc[tid]);
             }
             for (u32 i = head + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
-                const u64 k0 = key_of(i);
+                // (both owners, then both records: two LDS round trips per pair instead of four in a row)
+                const bool two = i + 1 < n_km;
+                u32 e0 = own[i], e1 = own[two ? i + 1 : i];
+                asm volatile("" : "+v"(e0), "+v"(e1));             // (both owner reads issued before either is used ...)
+                ull2_t r0 = lrec[e0 & 511u], r1 = lrec[e1 & 511u];
+                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r1.x), "+v"(r1.y));   // (... and both record reads: the compiler sinks the second pair into its branch otherwise)
+                const u64 k0 = key_cut(r0, e0);
                 if (SK_DBG(512)) {
                     if (k0 == 0x123456789ull)
                         ok[0] = k0;
-                } else if (i + 1 < n_km) {
+                } else if (two) {
                     ull2_t kk;
                     kk.x = k0;
-                    kk.y = key_of(i + 1);
+                    kk.y = key_cut(r1, e1);
                     SKQ_STORE(kk, reinterpret_cast<ull2_t *>(&ok[i]));
                     SKQ_STOREC((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
                 } else {
