@@ -56,3 +56,21 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(pkg.DnaGpuError) as ei:
         pkg.Context(0)
     assert ei.value.code == 7                     # DNAGPU_ERR_NO_DEVICE: fails loudly, no fallback
+
+
+def test_key_mix_is_a_bijection_of_the_key_bits(tmp_path):
+    """key_mix / key_unmix (kmer_device.hpp; the keys of the oversize buckets travel mixed through their tree and the groups
+    are turned back): a bijection of the 2k-bit keys for every k the engine takes, near-copies spread over the top digits.
+    Host code of the same header, built with hipcc: no device is touched."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "keymix_check")
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I",
+                           os.path.join(root, "dna-sequences-pg-extension_amd", "csrc"),
+                           os.path.join(root, "tests", "host", "keymix_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
