@@ -2339,27 +2339,43 @@ __global__ __launch_bounds__(SKQ_NT, 8) void sk_count_clean_kernel(const Node *_
                 SKQ_STORE(key_of((u32)tid), &ok[tid]);
                 SKQ_STOREC(1u, &oc[tid]);
             }
-            for (u32 i = head + 2u * (u32)tid; i < n_km; i += 2u * SKQ_NT) {
-                // (both owners, then both records: two LDS round trips per pair instead of four in a row)
-                const bool two = i + 1 < n_km;
-                u32 e0 = own[i], e1 = own[two ? i + 1 : i];
-                asm volatile("" : "+v"(e0), "+v"(e1));             // (both owner reads issued before either is used ...)
-                ull2_t r0 = lrec[e0 & 511u], r1 = lrec[e1 & 511u];
-                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r1.x), "+v"(r1.y));   // (... and both record reads: the compiler sinks the second pair into its branch otherwise)
-                const u64 k0 = key_cut(r0, e0);
+            // (both owners, then both records: two LDS round trips per pair instead of four in a row -- and the NEXT pair's
+            // reads are issued before this pair's keys are cut and stored)
+            u32 i = head + 2u * (u32)tid;
+            u32 e0 = 0, e1 = 0;
+            ull2_t r0, r1;
+            r0.x = r0.y = r1.x = r1.y = 0;
+            auto fetch = [&](u32 at) {
+                e0 = own[at];
+                e1 = own[at + 1 < n_km ? at + 1 : at];
+                asm volatile("" : "+v"(e0), "+v"(e1));
+                r0 = lrec[e0 & 511u];
+                r1 = lrec[e1 & 511u];
+                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r1.x), "+v"(r1.y));
+            };
+            if (i < n_km)
+                fetch(i);
+            while (i < n_km) {
+                const u32 ce0 = e0, ce1 = e1;
+                const ull2_t c0 = r0, c1 = r1;
+                const u32 nxt = i + 2u * SKQ_NT;
+                if (nxt < n_km)
+                    fetch(nxt);
+                const u64 k0 = key_cut(c0, ce0);
                 if (SK_DBG(512)) {
                     if (k0 == 0x123456789ull)
                         ok[0] = k0;
-                } else if (two) {
+                } else if (i + 1 < n_km) {
                     ull2_t kk;
                     kk.x = k0;
-                    kk.y = key_cut(r1, e1);
+                    kk.y = key_cut(c1, ce1);
                     SKQ_STORE(kk, reinterpret_cast<ull2_t *>(&ok[i]));
                     SKQ_STOREC((u64)0x100000001ull, reinterpret_cast<u64 *>(&oc[i]));
                 } else {
                     SKQ_STORE(k0, &ok[i]);
                     SKQ_STOREC(1u, &oc[i]);
                 }
+                i = nxt;
             }
             if (tid == 0) {
                 seg_off[li] = off;
