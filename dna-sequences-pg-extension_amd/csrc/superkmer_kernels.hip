@@ -415,6 +415,50 @@ __device__ __forceinline__ void sk_records(const SkFront<W> &f, const Keys &key,
     }
 }
 
+// A FULL tile whose rows all have ONE minimum m-mer value -- poly-A, a microsatellite (the smallest rotation of the unit is
+// every window's minimum), a tandem repeat shorter than a window -- needs no walk: by value it is one run, cut every lmax
+// rows from the tile's first (exactly what the general walk makes of it, at a few percent of its cost: a sequence that is
+// half poly-A spent 5.5 + 7.3 ms in the two level-0 kernels' walks).  Returns that value, or ~0u where the tile is no such
+// tile (no m-mer value is all ones).  Equal hashes first (cheap; unequal ones settle it), then the values themselves, cut from
+// the lane's bases at every row's minimum: a hash of 25 bits does not vouch for them.  All lanes of the wave call it.
+template <int W, bool BATCH>
+__device__ __forceinline__ u32 sk_uniform_value(const SkFront<W> &f, const u64 *__restrict__ words, u64 n_words, u64 pos0, u32 mmask)
+{
+    const int lane = threadIdx.x & 63;
+    // (called over the MEMORY copy of the front the general walk takes, loops rolled eight rows at a time: over the front's
+    // registers, fully unrolled, it cost sk_scatter0 70 spilled registers and sk_hist0 a wave per SIMD)
+    u32 x = 0, y = f.hm[0];
+#pragma unroll 2
+    for (int j = 1; j < 32; j++) {
+        x |= f.hm[j] ^ f.hm[0];
+        if (BATCH)
+            y &= f.hm[j];
+    }
+    const u32 h0 = (u32)__builtin_amdgcn_readfirstlane((int)f.hm[0]) >> 7;
+    // (BATCH: bit 6 is clear in the minimum of a row that reaches across a sequence start -- such a tile is not uniform)
+    const bool same = lane == 63 || ((x >> 7) == 0 && (f.hm[0] >> 7) == h0 && (!BATCH || (y & 64u)));
+    if (__ballot(!same))
+        return ~0u;
+    const u64 pos = pos0 + (u64)lane * 32;
+    const u64 w = pos >> 5;
+    const unsigned sh = (unsigned)(pos & 31) * 2;
+    const u64 w0 = w < n_words ? words[w] : 0, w1 = w + 1 < n_words ? words[w + 1] : 0;
+    u64 lo = w0, hi = w1;
+    if (sh) {
+        const u64 w2 = w + 2 < n_words ? words[w + 2] : 0;
+        lo = (w0 >> sh) | (w1 << (64 - sh));
+        hi = (w1 >> sh) | (w2 << (64 - sh));
+    }
+    const u32 v0 = (u32)sk_shr128(lo, hi, 2u * (f.hm[0] & SK_GPOS_MASK)) & mmask;
+    u32 d = 0;
+#pragma unroll 2
+    for (int j = 1; j < 32; j++)
+        d |= ((u32)sk_shr128(lo, hi, 2u * (f.hm[j] & SK_GPOS_MASK)) & mmask) ^ v0;
+    const u32 V = (u32)__builtin_amdgcn_readfirstlane((int)v0);
+    const bool ok = lane == 63 || (d == 0 && v0 == V);
+    return __ballot(!ok) ? ~0u : V;
+}
+
 // The general walk of sk_hist0 over a MEMORY copy of the front, its loops over the rows unrolled eight at a time: non-plain
 // tiles are rare (none on random sequence), and fully unrolled over the front's registers the walk's registers were the
 // kernel's (85 -> 128 VGPRs with spills: one wave less per SIMD for every tile).  (As a function of its own -- tried -- every
@@ -478,8 +522,14 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_hist0_kernel(const Chunk *__restr
                 }
             }
         } else {
-            SkFront<W> fm = f;                     // (a copy in memory for the walk: f itself stays in registers)
-            sk_hist0_general<W, BATCH>(fm, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
+            SkFront<W> fm = f;                     // (a copy in memory for what follows: f itself stays in registers)
+            const u32 uv = fm.plain ? sk_uniform_value<W, BATCH>(fm, words, n_words, first + ch.off + t0, mmask) : ~0u;
+            if (uv != ~0u) {                       // one run of one m-mer value: its records are the cuts every lmax rows
+                if (lane == 0)
+                    atomicAdd(&h[sk_digit0(sk_digit_word(fm.hm[0]), c0n)], ((u32)SKW_ROWS + lmax - 1u) / lmax);
+            } else {
+                sk_hist0_general<W, BATCH>(fm, words, n_words, first + ch.off + t0, lmax, mmask, c0n, h);
+            }
         }
     }
     __syncthreads();
@@ -731,10 +781,24 @@ __global__ __launch_bounds__(SK_NT, 4) void sk_scatter0_kernel(const Chunk *__re
         }
         // the general walk: a partial tile, or one of too many (hash, position) runs
         {
-            SkFront<W> fm = f;                     // (a copy in memory for it: f itself stays in registers)
+            SkFront<W> fm = f;                     // (a copy in memory for what follows: f itself stays in registers)
             const SkBuild bm = bx;
-            if (sk_scatter0_general<W, BATCH>(fm, bm, words, n_words, tile_pos, lmax))
+            const u32 uv = fm.plain ? sk_uniform_value<W, BATCH>(fm, words, n_words, tile_pos, mmask) : ~0u;
+            if (uv != ~0u) {
+                // one run of one m-mer value (sk_uniform_value): the records the walk by value would list -- value << 32 |
+                // start row << 16 | end row, cut every lmax rows -- written directly
+                const u32 n_rec = ((u32)SKW_ROWS + lmax - 1u) / lmax;
+                for (u32 e = (u32)lane; e < n_rec; e += 64) {
+                    const u32 s0 = e * lmax, e1 = (s0 + lmax < (u32)SKW_ROWS ? s0 + lmax : (u32)SKW_ROWS) - 1u;
+                    wl[e] = ((u64)uv << 32) | (u64)((s0 << 16) | e1);
+                }
+                sk_wave_fence();
+                if (sk_build<BATCH>(bm, n_rec, 0))
+                    dropped = true;
+                sk_wave_fence();
+            } else if (sk_scatter0_general<W, BATCH>(fm, bm, words, n_words, tile_pos, lmax)) {
                 dropped = true;
+            }
         }
     }
     if (slab) {
